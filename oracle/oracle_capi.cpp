@@ -1,0 +1,356 @@
+// CPU ORACLE -- TEST INFRASTRUCTURE ONLY.
+//
+// C entry points over slam_oracle.hpp so that Python tests (ctypes) and the
+// benchmark's cpu_baseline leg can drive the restated reference algorithm.
+// Not part of the shipped library; see the header of slam_oracle.hpp.
+#include <cstring>
+#include <random>
+#include <thread>
+
+#include "slam_oracle.hpp"
+
+using namespace oracle;
+
+namespace {
+
+struct world {
+  // Input in "ready to replay" form: one model per control / observation, the
+  // observations in arrival order (sorted by timestep, stable).
+  std::vector<velocity_slip_model> controls;
+  struct obs_in {
+    std::size_t t, id;
+    range_only_model model;
+  };
+  std::vector<obs_in> obs;
+
+  slam_data data;
+  std::unique_ptr<slam_initialiser> init;
+  std::vector<std::unique_ptr<mcmc_slam>> chains;
+  std::vector<std::vector<step_record>> traces;
+  std::size_t replayed_upto = 0;  // next timestep to feed
+  bool started = false;
+  std::size_t next_obs = 0;
+  std::string error;
+};
+
+// Feed events exactly in the order of slam_data::add_dataset
+// (src/slam/slam_data.hpp:191-215), up to and including timestep `upto`.
+void replay(world& w, std::size_t upto, bool finish) {
+  std::size_t& oi = w.next_obs;  // first not-yet-fed observation
+  auto feed_obs = [&](std::size_t t) {
+    while (oi < w.obs.size() && w.obs[oi].t == t) {
+      w.data.add_observation(w.obs[oi].id, w.obs[oi].model);
+      ++oi;
+    }
+  };
+  if (!w.started) {
+    feed_obs(0);
+    w.data.timestep(0);
+    w.started = true;
+    w.replayed_upto = 1;
+  }
+  while (w.replayed_upto <= upto && w.data.current_timestep() < w.controls.size()) {
+    w.data.add_control(w.controls[w.data.current_timestep()]);
+    feed_obs(w.data.current_timestep());
+    w.data.timestep(w.data.current_timestep());
+    w.replayed_upto = w.data.current_timestep() + 1;
+  }
+  if (finish) w.data.completed();
+}
+
+}  // namespace
+
+extern "C" {
+
+struct ora_record {
+  std::int32_t kind;
+  std::int32_t accepted;
+  std::uint64_t index;
+  double proposed[3];
+  double log_ratio;
+  double log_likelihood;
+};
+
+void* ora_world_new() { return new world(); }
+void ora_world_free(void* p) { delete static_cast<world*>(p); }
+
+int ora_world_set_input(void* p, std::uint32_t T, const double* cmean, const double* cstd, std::uint32_t N,
+                        const std::uint32_t* obs_t, const std::uint32_t* obs_id, const double* obs_mean,
+                        const double* obs_std) {
+  world& w = *static_cast<world*>(p);
+  w.controls.resize(T);
+  for (std::uint32_t t = 0; t < T; ++t)
+    for (int i = 0; i < 3; ++i) {
+      w.controls[t].mean[i] = cmean[3 * t + i];
+      w.controls[t].stddev[i] = cstd[3 * t + i];
+    }
+  w.obs.resize(N);
+  for (std::uint32_t i = 0; i < N; ++i) {
+    if (i > 0 && obs_t[i] < obs_t[i - 1]) return -1;
+    w.obs[i].t = obs_t[i];
+    w.obs[i].id = obs_id[i];
+    w.obs[i].model.mean[0] = obs_mean[i];
+    w.obs[i].model.stddev[0] = obs_std[i];
+  }
+  return 0;
+}
+
+// Plaza loader (src/dataset.cpp:17-112) followed by the model builders, as
+// slam_data::add_dataset would apply them.  alphas == NULL -> the defaults of
+// src/planar_robot/velocity_model.cpp:23-32.
+int ora_world_load_plaza(void* p, const char* dir, const char* name, double range_stddev, const double* alphas) {
+  world& w = *static_cast<world*>(p);
+  try {
+    const dataset d = read_range_only_data(dir, name);
+    const velocity_slip_model::builder cb =
+        alphas ? velocity_slip_model::builder(alphas[0], alphas[1], alphas[2], alphas[3], alphas[4], alphas[5])
+               : velocity_slip_model::builder::defaults();
+    const range_only_model::builder ob(range_stddev);
+    w.controls.clear();
+    for (std::size_t t = 0; t < d.current_timestep(); ++t) w.controls.push_back(cb(d.controls[t].data(), d.timedelta(t)));
+    w.obs.clear();
+    for (const auto& o : d.observations) w.obs.push_back({o.t, o.id, ob(o.range)});
+  } catch (const std::exception& e) {
+    w.error = e.what();
+    return -1;
+  }
+  return 0;
+}
+
+void ora_world_dims(void* p, std::uint32_t* T, std::uint32_t* N) {
+  world& w = *static_cast<world*>(p);
+  *T = std::uint32_t(w.controls.size());
+  *N = std::uint32_t(w.obs.size());
+}
+
+void ora_world_get_input(void* p, double* cmean, double* cstd, std::uint32_t* obs_t, std::uint32_t* obs_id,
+                         double* obs_mean, double* obs_std) {
+  world& w = *static_cast<world*>(p);
+  for (std::size_t t = 0; t < w.controls.size(); ++t)
+    for (int i = 0; i < 3; ++i) {
+      cmean[3 * t + i] = w.controls[t].mean[i];
+      cstd[3 * t + i] = w.controls[t].stddev[i];
+    }
+  for (std::size_t i = 0; i < w.obs.size(); ++i) {
+    obs_t[i] = std::uint32_t(w.obs[i].t);
+    obs_id[i] = std::uint32_t(w.obs[i].id);
+    obs_mean[i] = w.obs[i].model.mean[0];
+    obs_std[i] = w.obs[i].model.stddev[0];
+  }
+}
+
+// Must be called before the first replay: registers the dead-reckoning
+// initialiser as the first listener (src/main.cpp:182-183).
+int ora_world_set_initialiser(void* p, std::uint32_t init_seed) {
+  world& w = *static_cast<world*>(p);
+  if (w.started || w.init) return -1;
+  w.init = std::make_unique<slam_initialiser>(&w.data, init_seed);
+  w.data.add_listener(w.init.get());
+  return 0;
+}
+
+// Adds one chain (src/main.cpp:188-193 when use_initialiser, else the way
+// multi_mcmc builds its chains, src/slam/multi_mcmc.hpp:164-166).
+int ora_world_add_chain(void* p, std::uint32_t seed, std::uint32_t steps_per_timestep, std::uint32_t end_steps,
+                        int use_initialiser, int uniform_first) {
+  world& w = *static_cast<world*>(p);
+  if (w.started) return -1;
+  auto c = std::make_unique<mcmc_slam>(&w.data, seed);
+  c->steps_per_timestep = steps_per_timestep;
+  c->end_steps = end_steps;
+  c->uniform_first = uniform_first != 0;
+  if (use_initialiser) {
+    if (!w.init) return -2;
+    c->set_initialiser(w.init.get());
+  }
+  w.data.add_timestep_listener(c.get());
+  w.chains.push_back(std::move(c));
+  w.traces.emplace_back();
+  return int(w.chains.size()) - 1;
+}
+
+void ora_chain_trace_enable(void* p, int chain) {
+  world& w = *static_cast<world*>(p);
+  w.chains[chain]->trace = &w.traces[chain];
+}
+
+// Feeds the data up to timestep `upto` (inclusive); finish != 0 also signals
+// completed() (which runs each chain's end_steps).
+int ora_world_replay(void* p, std::uint32_t upto, int finish) {
+  world& w = *static_cast<world*>(p);
+  try {
+    replay(w, upto, finish != 0);
+  } catch (const std::exception& e) {
+    w.error = e.what();
+    return -1;
+  }
+  return 0;
+}
+
+int ora_chain_update(void* p, int chain, std::uint32_t nsteps) {
+  world& w = *static_cast<world*>(p);
+  int accepted = 0;
+  for (std::uint32_t i = 0; i < nsteps; ++i) accepted += w.chains[chain]->update() ? 1 : 0;
+  return accepted;
+}
+
+// Steps every chain `nsteps` times using `nthreads` host threads (chains are
+// independent); returns the total number of loop-body executions
+// (src/slam/mcmc_slam.hpp:487-502) performed by the call.
+std::uint64_t ora_world_update_all(void* p, std::uint32_t nsteps, std::uint32_t nthreads) {
+  world& w = *static_cast<world*>(p);
+  std::uint64_t before = 0;
+  for (auto& c : w.chains) before += c->units;
+  const std::size_t n = w.chains.size();
+  nthreads = std::max<std::uint32_t>(1, std::min<std::uint32_t>(nthreads, std::uint32_t(n)));
+  std::vector<std::thread> pool;
+  for (std::uint32_t k = 0; k < nthreads; ++k)
+    pool.emplace_back([&, k]() {
+      for (std::size_t c = k; c < n; c += nthreads)
+        for (std::uint32_t i = 0; i < nsteps; ++i) w.chains[c]->update();
+    });
+  for (auto& t : pool) t.join();
+  std::uint64_t after = 0;
+  for (auto& c : w.chains) after += c->units;
+  return after - before;
+}
+
+std::uint32_t ora_chain_trace_size(void* p, int chain) {
+  return std::uint32_t(static_cast<world*>(p)->traces[chain].size());
+}
+
+void ora_chain_trace_get(void* p, int chain, std::uint32_t start, std::uint32_t count, ora_record* out) {
+  world& w = *static_cast<world*>(p);
+  for (std::uint32_t i = 0; i < count; ++i) {
+    const step_record& r = w.traces[chain][start + i];
+    out[i].kind = r.kind;
+    out[i].accepted = r.accepted;
+    out[i].index = r.index;
+    std::memcpy(out[i].proposed, r.proposed, sizeof r.proposed);
+    out[i].log_ratio = r.log_ratio;
+    out[i].log_likelihood = r.log_likelihood;
+  }
+}
+
+double ora_chain_log_likelihood(void* p, int chain) { return static_cast<world*>(p)->chains[chain]->get_log_likelihood(); }
+
+double ora_chain_full_log_likelihood(void* p, int chain) {
+  world& w = *static_cast<world*>(p);
+  return slam_log_likelihood(w.data, *w.chains[chain]);
+}
+
+std::uint64_t ora_chain_units(void* p, int chain) { return static_cast<world*>(p)->chains[chain]->units; }
+
+void ora_chain_dims(void* p, int chain, std::uint32_t* T, std::uint32_t* F) {
+  world& w = *static_cast<world*>(p);
+  *T = std::uint32_t(w.chains[chain]->current_timestep());
+  *F = std::uint32_t(w.chains[chain]->features().size());
+}
+
+// rel[3*t..] = relative pose of edge t as the reference reads it back
+// (bitree::get); cum[3*k..] = accumulate(k), k = 0..T; features in
+// feature_estimates order (order of first observation).
+void ora_chain_get_state(void* p, int chain, double* rel, double* cum, std::uint32_t* feat_id,
+                         std::uint32_t* feat_parent, double* feat_est, double* state_w, double* feat_w) {
+  world& w = *static_cast<world*>(p);
+  mcmc_slam& c = *w.chains[chain];
+  const auto& tr = c.get_trajectory();
+  const std::size_t T = tr.size();
+  for (std::size_t t = 0; t < T; ++t) {
+    if (rel) {
+      const pose d = tr.get(t);
+      rel[3 * t] = d.x;
+      rel[3 * t + 1] = d.y;
+      rel[3 * t + 2] = d.th;
+    }
+    if (state_w) state_w[t] = c.get_state_weights().get(t);
+  }
+  if (cum)
+    for (std::size_t k = 0; k <= T; ++k) {
+      const pose a = tr.accumulate(k);
+      cum[3 * k] = a.x;
+      cum[3 * k + 1] = a.y;
+      cum[3 * k + 2] = a.th;
+    }
+  const auto& fs = c.features();
+  for (std::size_t i = 0; i < fs.size(); ++i) {
+    if (feat_id) feat_id[i] = std::uint32_t(fs[i].id);
+    if (feat_parent) feat_parent[i] = std::uint32_t(fs[i].parent_timestep);
+    if (feat_est) {
+      feat_est[2 * i] = fs[i].estimate.x;
+      feat_est[2 * i + 1] = fs[i].estimate.y;
+    }
+    if (feat_w) feat_w[i] = c.get_feature_weights().get(i);
+  }
+}
+
+// Weight-tree nodes exactly as stored (bit-for-bit), for exact comparisons.
+void ora_chain_get_weight_nodes(void* p, int chain, double* state_nodes, double* feat_nodes) {
+  world& w = *static_cast<world*>(p);
+  mcmc_slam& c = *w.chains[chain];
+  const auto& s = c.get_state_weights().raw();
+  const auto& f = c.get_feature_weights().raw();
+  if (state_nodes) std::memcpy(state_nodes, s.data(), s.size() * sizeof(double));
+  if (feat_nodes) std::memcpy(feat_nodes, f.data(), f.size() * sizeof(double));
+}
+
+void ora_chain_get_rng(void* p, int chain, std::uint32_t* mt, std::int32_t* idx, std::int32_t* has_saved,
+                       double* saved) {
+  world& w = *static_cast<world*>(p);
+  random_source& r = w.chains[chain]->rng();
+  std::memcpy(mt, r.raw_engine().state(), 624 * sizeof(std::uint32_t));
+  *idx = r.raw_engine().index();
+  *has_saved = r.has_saved() ? 1 : 0;
+  *saved = r.saved_value();
+}
+
+double ora_chain_eval(void* p, int chain, int kind, std::uint32_t index, const double* proposed) {
+  world& w = *static_cast<world*>(p);
+  mcmc_slam& c = *w.chains[chain];
+  const std::uint64_t u = c.units;
+  double r;
+  if (kind == 0)
+    r = c.eval_state_edge(index, pose::cartesian(proposed[0], proposed[1], proposed[2]));
+  else
+    r = c.eval_feature_edge(index, position::cartesian(proposed[0], proposed[1]));
+  c.units = u;
+  return r;
+}
+
+// n successive 32-bit engine draws from random_source(seed): the chain seeds
+// of multi_mcmc (src/slam/multi_mcmc.hpp:160-166) and the module seeds of
+// src/main.cpp:133-147.
+void ora_seed_sequence(std::uint32_t seed, std::uint32_t n, std::uint32_t* out) {
+  random_source r(seed);
+  for (std::uint32_t i = 0; i < n; ++i) out[i] = r();
+}
+
+// Draw n uniforms from random_source(seed) (what slam_initialiser consumes, one
+// per new feature: src/slam/slam_initialiser.hpp:44-47).
+void ora_uniform_sequence(std::uint32_t seed, std::uint32_t n, double* out) {
+  random_source r(seed);
+  for (std::uint32_t i = 0; i < n; ++i) out[i] = r.uniform();
+}
+
+// Self-test: the explicit engine/distributions against this container's
+// libstdc++ (what the reference's random_source would use here).  Returns the
+// number of mismatching draws out of 3*n.
+int ora_selftest_rng(std::uint32_t seed, std::uint32_t n) {
+  random_source mine(seed);
+  std::mt19937 eng(seed);
+  std::uniform_real_distribution<> ud;
+  std::normal_distribution<> nd;
+  int bad = 0;
+  for (std::uint32_t i = 0; i < n; ++i) {
+    // interleave the three kinds of draw as the sampler does
+    if (mine.uniform() != ud(eng)) ++bad;
+    if (mine.normal() != nd(eng)) ++bad;
+    if (i % 3 == 0 && mine() != eng()) ++bad;
+    if (mine.normal() != nd(eng)) ++bad;
+  }
+  return bad;
+}
+
+const char* ora_world_error(void* p) { return static_cast<world*>(p)->error.c_str(); }
+
+}  // extern "C"

@@ -1,0 +1,965 @@
+// CPU ORACLE -- TEST INFRASTRUCTURE ONLY.
+//
+// Dependency-free C++17 restatement of the reference's MCMC-SLAM proposal
+// evaluation path (reference tree: /root/reference, all file:line citations
+// are relative to it).  Nothing in the shipped GPU path may include, link or
+// call this file; it exists so that tests and the benchmark's cpu_baseline leg
+// have an independent statement of the reference algorithm to compare with.
+//
+// Parity status: the generic tree (`bitree`) is pinned by the reference's own
+// known-answer program test/bitree.cpp (restated in bitree_kat.cpp).  The
+// sampler, the models and the loader have NO golden vectors in the reference
+// and the reference itself cannot be built here (it needs Eigen3, Boost and
+// g2o, none of which are installed), so for those parts parity is UNPINNED:
+// they are a careful operation-by-operation restatement only.
+//
+// Third-party arithmetic restated explicitly (so results do not depend on the
+// standard library or on Eigen/Boost being present):
+//   * Eigen::Rotation2Dd * Vector2d    -> [c -s; s c] * v with c,s = cos,sin(angle)
+//   * Vector::squaredNorm / sum        -> left-to-right sums (unpinned: Eigen's
+//     reduction order for 3-vectors depends on its version/vectorisation)
+//   * boost::math::constants::pi       -> the double nearest to pi
+//   * std::mt19937, generate_canonical<double,53>, normal_distribution (libstdc++
+//     11: /usr/include/c++/11/bits/random.tcc:1802-1835, 3345-3380)
+//
+// Build with -ffp-contract=off: the reference is built -mno-avx (no FMA),
+// src/CMakeLists.txt:55.
+#ifndef SLAM_ORACLE_HPP
+#define SLAM_ORACLE_HPP
+
+#include <algorithm>
+#include <array>
+#include <cassert>
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <fstream>
+#include <functional>
+#include <iostream>
+#include <map>
+#include <memory>
+#include <set>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace oracle {
+
+constexpr double kPi = 3.14159265358979323846264338327950288;
+
+// src/utility/geometry.hpp:8-16
+inline double wrap_angle(double angle) {
+  angle = std::fmod(angle, 2.0 * kPi);
+  if (angle < -kPi)
+    angle += 2.0 * kPi;
+  else if (angle >= kPi)
+    angle -= 2.0 * kPi;
+  return angle;
+}
+
+// ---------------------------------------------------------------------------
+// src/planar_robot/position.hpp:12-47
+struct position {
+  double x = 0.0, y = 0.0;
+  static position cartesian(double x, double y) { return {x, y}; }
+  // position.hpp:27-29
+  static position polar(double dist, double dir) {
+    return {dist * std::cos(dir), dist * std::sin(dir)};
+  }
+  double distance_squared() const { return x * x + y * y; }          // :35
+  double distance() const { return std::sqrt(distance_squared()); }  // :33
+  double direction() const { return std::atan2(y, x); }              // :34
+};
+
+// src/planar_robot/pose.hpp:16-87.  The rotation is stored as an angle only
+// (Eigen::Rotation2Dd), so every application recomputes sin and cos.
+struct pose {
+  double x = 0.0, y = 0.0, th = 0.0;
+  static pose cartesian(double x, double y, double b) { return {x, y, b}; }
+  double bearing() const { return th; }
+  double distance_squared() const { return x * x + y * y; }
+
+  // pose.hpp:67-71   translation += R(th) * p.translation; th += p.th
+  pose& operator+=(const pose& p) {
+    const double s = std::sin(th), c = std::cos(th);
+    const double rx = c * p.x - s * p.y;
+    const double ry = s * p.x + c * p.y;
+    x += rx;
+    y += ry;
+    th += p.th;  // angles are added, never wrapped
+    return *this;
+  }
+  // pose.hpp:73-76   (R(-th) * (-t), -th)
+  pose operator-() const {
+    const double ith = -th;
+    const double s = std::sin(ith), c = std::cos(ith);
+    const double nx = -x, ny = -y;
+    return {c * nx - s * ny, s * nx + c * ny, ith};
+  }
+};
+inline pose operator+(pose a, const pose& b) { return a += b; }  // pose.hpp:81-83
+// pose.hpp:85-87
+inline position operator+(const pose& p, const position& o) {
+  const double s = std::sin(p.th), c = std::cos(p.th);
+  const double rx = c * o.x - s * o.y;
+  const double ry = s * o.x + c * o.y;
+  return {p.x + rx, p.y + ry};
+}
+
+// ---------------------------------------------------------------------------
+// src/utility/bitree.hpp -- binary indexed tree over a (non-commutative) group.
+namespace bt {
+inline std::size_t parent(std::size_t i) { return i & (i - 1); }             // :17-19
+inline std::size_t next_sibling(std::size_t i) { return i + (i & (~i + 1)); }  // :24-26
+inline std::size_t suffix_mask(std::size_t i) {                              // :29-37
+  i |= i >> 1;
+  i |= i >> 2;
+  i |= i >> 4;
+  i |= i >> 8;
+  i |= i >> 16;
+  i |= i >> 32;
+  return i;
+}
+inline std::size_t common_ancestor(std::size_t a, std::size_t b) {  // :40-42
+  return a & ~suffix_mask(a ^ b);
+}
+inline std::size_t child_containing(std::size_t p, std::size_t i) {  // :45-48
+  return i & ~(suffix_mask(p ^ i) >> 1);
+}
+}  // namespace bt
+
+template <class G>
+class bitree {
+  std::vector<G> el;  // el[i] = v[parent(i)+1] + ... + v[i]   (el[0] = v[0])
+
+  // :219-231
+  G accumulate_relative(std::size_t i, std::size_t ancestor) const {
+    G result = G();
+    for (; i != ancestor; i = bt::parent(i)) result = el[i] + result;
+    return result;
+  }
+  // :206-212
+  G parent_relative_value(std::size_t i, const G& value) const {
+    if (i == 0) return value;
+    return accumulate_relative(i - 1, bt::parent(i)) + value;
+  }
+  // :233-254
+  void update(std::size_t i, G new_value) {
+    if (i > 0)
+      for (std::size_t next; (next = bt::next_sibling(i)) < size(); i = next) {
+        G delta = new_value + (-el[i]);
+        el[i] = new_value;
+        const std::size_t next_parent = bt::parent(next);
+        while ((i = bt::parent(i)) != next_parent) delta = el[i] + delta + (-el[i]);
+        new_value = delta + el[next];
+      }
+    el[i] = new_value;
+  }
+
+ public:
+  std::size_t size() const { return el.size(); }
+  bool empty() const { return el.empty(); }
+  void clear() { el.clear(); }
+  void reserve(std::size_t n) { el.reserve(n); }
+  const std::vector<G>& raw() const { return el; }
+
+  // :256-264  reconstructs v[i]; lossy in floating point
+  G get(std::size_t i) const {
+    if (i == 0) return el[0];
+    return -accumulate_relative(i - 1, bt::parent(i)) + el[i];
+  }
+  G operator[](std::size_t i) const { return get(i); }
+  void set(std::size_t i, const G& v) { update(i, parent_relative_value(i, v)); }  // :214-216
+  void push_back(const G& v) { el.push_back(parent_relative_value(size(), v)); }   // :182-184
+  // :293-300
+  void push_back_accumulated(const G& v) {
+    if (empty())
+      el.push_back(v);
+    else
+      el.push_back(-accumulate(bt::parent(size()) + 1) + v);
+  }
+  // :274-291
+  G accumulate(std::size_t begin, std::size_t end) const {
+    if (begin == end) return G();
+    if (begin == 0) return el[0] + accumulate_relative(end - 1, 0);
+    if (end == 0) return -(el[0] + accumulate_relative(begin - 1, 0));
+    const std::size_t anc = bt::common_ancestor(begin - 1, end - 1);
+    return -accumulate_relative(begin - 1, anc) + accumulate_relative(end - 1, anc);
+  }
+  G accumulate(std::size_t end) const { return accumulate(0, end); }
+  G accumulate() const { return accumulate(size()); }
+  // :302-321 (ordered groups only)
+  std::size_t binary_search(const G& value) const {
+    if (el.empty() || value < el[0]) return 0;
+    std::size_t min = 0, max = el.size();
+    G origin = el[min];
+    while (min + 1 < max) {
+      const std::size_t mid = bt::child_containing(min, max - 1);
+      if (value < origin + el[mid])
+        max = mid;
+      else {
+        min = mid;
+        origin += el[min];
+      }
+    }
+    return max;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// src/utility/random.hpp:11-42 with the engine and both distributions written
+// out so the stream does not depend on <random>.
+class mt19937 {
+  std::uint32_t s[624];
+  int idx;
+  void refill() {
+    for (int i = 0; i < 624; ++i) {
+      const std::uint32_t y = (s[i] & 0x80000000u) | (s[(i + 1) % 624] & 0x7fffffffu);
+      s[i] = s[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    idx = 0;
+  }
+
+ public:
+  explicit mt19937(std::uint32_t seed = 5489u) { this->seed(seed); }
+  void seed(std::uint32_t seed) {
+    s[0] = seed;
+    for (int i = 1; i < 624; ++i) s[i] = 1812433253u * (s[i - 1] ^ (s[i - 1] >> 30)) + std::uint32_t(i);
+    idx = 624;
+  }
+  std::uint32_t operator()() {
+    if (idx >= 624) refill();
+    std::uint32_t y = s[idx++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+  }
+  const std::uint32_t* state() const { return s; }
+  int index() const { return idx; }
+};
+
+class random_source {
+  mt19937 engine;
+  bool saved_available = false;
+  double saved = 0.0;
+
+ public:
+  random_source() = default;
+  explicit random_source(std::uint32_t seed) : engine(seed) {}
+  std::uint32_t operator()() { return engine(); }  // random.hpp:26
+
+  // random.hpp:40 -> uniform_real_distribution<>(0,1) -> generate_canonical<double,53>:
+  // two 32-bit draws, (lo + hi * 2^32) / 2^64, clamped below 1 (random.tcc:3353-3379).
+  double uniform() {
+    double sum = 0.0, tmp = 1.0;
+    for (int k = 2; k != 0; --k) {
+      sum += double(engine()) * tmp;
+      tmp *= 4294967296.0;
+    }
+    double ret = sum / tmp;
+    if (ret >= 1.0) ret = std::nextafter(1.0, 0.0);
+    return ret;
+  }
+  // random.hpp:41 -> normal_distribution<>(0,1): Marsaglia polar, returns y*m
+  // and keeps x*m for the next call (random.tcc:1811-1831).
+  double normal() {
+    double ret;
+    if (saved_available) {
+      saved_available = false;
+      ret = saved;
+    } else {
+      double x, y, r2;
+      do {
+        x = 2.0 * uniform() - 1.0;
+        y = 2.0 * uniform() - 1.0;
+        r2 = x * x + y * y;
+      } while (r2 > 1.0 || r2 == 0.0);
+      const double mult = std::sqrt(-2 * std::log(r2) / r2);
+      saved = x * mult;
+      saved_available = true;
+      ret = y * mult;
+    }
+    return ret * 1.0 + 0.0;
+  }
+  const mt19937& raw_engine() const { return engine; }
+  bool has_saved() const { return saved_available; }
+  double saved_value() const { return saved; }
+};
+
+// ---------------------------------------------------------------------------
+// src/utility/random.hpp:44-129,230-268 -- independent normal in N dimensions.
+template <int N>
+struct independent_normal {
+  double mean[N];
+  double stddev[N];
+  // :94-100  z_i = normal() in index order, then z*sigma + mu
+  void sample(random_source& random, double* out) const {
+    for (int i = 0; i < N; ++i) out[i] = random.normal();
+    for (int i = 0; i < N; ++i) out[i] *= stddev[i];
+    for (int i = 0; i < N; ++i) out[i] += mean[i];
+  }
+  // :103-107, :116-121, :262-264  (subtract == plain difference for both
+  // compiled models: velocity_model.hpp:32-35, range_bearing_model.hpp:130-133)
+  double log_likelihood(const double* xin) const {
+    double x[N];
+    for (int i = 0; i < N; ++i) x[i] = xin[i] - mean[i];
+    for (int i = 0; i < N; ++i) x[i] /= stddev[i];
+    double sq = x[0] * x[0];
+    for (int i = 1; i < N; ++i) sq += x[i] * x[i];
+    const double exponent = -0.5 * sq;
+    const double log_root_two_pi = 0.5 * std::log(2 * kPi);
+    double log_det = std::log(stddev[0]);
+    for (int i = 1; i < N; ++i) log_det += std::log(stddev[i]);
+    return exponent - N * log_root_two_pi - log_det;
+  }
+};
+
+// src/planar_robot/velocity_model.hpp:22-182
+struct velocity_slip_model : independent_normal<3> {
+  static constexpr int vector_dim = 3;
+  // :37-49
+  static void observe(const pose& dp, double* out) {
+    const double r = 0.5 * dp.distance_squared() / dp.y;
+    if (std::isfinite(r)) {
+      const double alpha = r >= 0 ? std::atan2(dp.x, r - dp.y) : std::atan2(-dp.x, dp.y - r);
+      out[0] = r * alpha;
+      out[1] = alpha;
+      out[2] = wrap_angle(dp.bearing() - alpha);
+    } else {
+      out[0] = dp.x;
+      out[1] = 0.0;
+      out[2] = dp.bearing();
+    }
+  }
+  // :51-63
+  static pose inv_observe(const double* control) {
+    const double s = control[0], alpha = control[1], beta = control[2], r = s / alpha;
+    if (std::isfinite(r))
+      return pose::cartesian(r * std::sin(alpha), r - r * std::cos(alpha), alpha + beta);
+    return pose::cartesian(s, 0.0, beta);
+  }
+  // proposal_dist :131-153
+  static constexpr int proposal_dim = 3;
+  pose propose(random_source& random) const {
+    double v[3];
+    sample(random, v);
+    return inv_observe(v);
+  }
+  double proposal_log_likelihood(const pose& x) const {
+    double v[3];
+    observe(x, v);
+    return log_likelihood(v);
+  }
+  pose proposal_initial_value(random_source&) const { return inv_observe(mean); }
+  double log_likelihood_of(const pose& x) const { return proposal_log_likelihood(x); }
+
+  // builder :157-181 -- mean = dt*u ; stddev = dt * sqrt((dt*A) * u^2)
+  struct builder {
+    double A[3][3];
+    builder(double a1, double a2, double a3, double a4, double a5, double a6)
+        : A{{a1, a2, 0}, {a3, a4, 0}, {a5, a6, 0}} {}
+    // defaults: velocity_model.cpp:23-32
+    static builder defaults() {
+      const double RAD_PER_DEG = kPi / 180;
+      return builder(0.01, 0.0, 1.0 * RAD_PER_DEG * RAD_PER_DEG, 0.01, 0.01 * RAD_PER_DEG * RAD_PER_DEG,
+                     0.001 * RAD_PER_DEG);
+    }
+    velocity_slip_model operator()(const double* control, double dt) const {
+      velocity_slip_model m;
+      double sq[3];
+      for (int j = 0; j < 3; ++j) sq[j] = control[j] * control[j];
+      for (int i = 0; i < 3; ++i) {
+        m.mean[i] = dt * control[i];
+        double acc = (dt * A[i][0]) * sq[0];
+        acc += (dt * A[i][1]) * sq[1];
+        acc += (dt * A[i][2]) * sq[2];
+        m.stddev[i] = dt * std::sqrt(acc);
+      }
+      return m;
+    }
+  };
+};
+
+// src/planar_robot/range_bearing_model.hpp:119-196
+struct range_only_model : independent_normal<1> {
+  static constexpr int vector_dim = 1;
+  static double observe(const position& p) { return p.distance(); }  // :135-139
+  // :141-143
+  bool more_accurate_than(const range_only_model& o) const { return std::abs(mean[0]) < std::abs(o.mean[0]); }
+  double log_likelihood_of(const position& p) const {
+    const double r = observe(p);
+    return log_likelihood(&r);
+  }
+  // proposal_dist :145-176.  The two arguments of position::polar() at :157-158
+  // are unsequenced in the reference; g++ 11 evaluates the uniform first, clang
+  // the normal first.  `uniform_first` selects which.
+  static constexpr int proposal_dim = 2;  // :151
+  position propose(random_source& random, bool uniform_first) const {
+    double r, u;
+    if (uniform_first) {
+      u = random.uniform();
+      sample(random, &r);
+    } else {
+      sample(random, &r);
+      u = random.uniform();
+    }
+    return position::polar(r, u * 2 * kPi);
+  }
+  double proposal_log_likelihood(const position& x) const {  // :166-169
+    return log_likelihood_of(x) - std::log(2 * kPi);
+  }
+  position proposal_initial_value(random_source& random) const {  // :171-175
+    return position::polar(mean[0], random.uniform() * 2 * kPi);
+  }
+  struct builder {  // :180-195
+    double stddev;
+    explicit builder(double s) : stddev(s) {}
+    range_only_model operator()(double observation) const {
+      range_only_model m;
+      m.mean[0] = observation;
+      m.stddev[0] = stddev;
+      return m;
+    }
+  };
+};
+
+// ---------------------------------------------------------------------------
+// Raw dataset: src/slam/dataset_impl.hpp:20-85 (+ interfaces.hpp:130-154)
+struct raw_observation {
+  std::size_t t;
+  std::size_t id;
+  double range;
+};
+struct dataset {
+  std::vector<std::array<double, 3>> controls;  // raw (v, w, 0)
+  bitree<double> timedeltas;
+  std::vector<raw_observation> observations;  // kept sorted by t, stable (flat_multimap)
+
+  std::size_t current_timestep() const { return controls.size(); }
+  double timedelta(std::size_t t) const { return timedeltas[t]; }                     // :48-50
+  std::size_t timestep_at(double ts) const { return timedeltas.binary_search(ts); }  // :56-58
+  void add_control(double dt, const std::array<double, 3>& c) {                      // :71-74
+    timedeltas.push_back(dt);
+    controls.push_back(c);
+  }
+  // :76-79  flat_multimap::emplace inserts after existing equal keys
+  void add_observation(std::size_t t, std::size_t id, double range) {
+    auto it = std::upper_bound(observations.begin(), observations.end(), t,
+                               [](std::size_t v, const raw_observation& o) { return v < o.t; });
+    observations.insert(it, raw_observation{t, id, range});
+  }
+  std::pair<std::size_t, std::size_t> observations_at(std::size_t t) const {
+    auto lo = std::lower_bound(observations.begin(), observations.end(), t,
+                               [](const raw_observation& o, std::size_t v) { return o.t < v; });
+    auto hi = std::upper_bound(observations.begin(), observations.end(), t,
+                               [](std::size_t v, const raw_observation& o) { return v < o.t; });
+    return {std::size_t(lo - observations.begin()), std::size_t(hi - observations.begin())};
+  }
+};
+
+// src/dataset.cpp:17-112 -- Plaza range-only text loader (ground truth and the
+// controls.txt side effect are not part of the path and are left out; only the
+// GT file's first row is read: it defines the start time, :34-36).
+inline dataset read_range_only_data(const std::string& dir, const std::string& name) {
+  dataset d;
+  double start_timestamp;
+  {
+    std::ifstream gt(dir + "/" + name + "/" + name + "_GT.txt");
+    if (!gt) throw std::runtime_error("cannot open " + name + "_GT.txt under " + dir);
+    double t, x, y, b;
+    gt >> t >> x >> y >> b;
+    start_timestamp = t;
+  }
+  {  // :65-76
+    std::ifstream dr(dir + "/" + name + "/" + name + "_DR.txt");
+    if (!dr) throw std::runtime_error("cannot open " + name + "_DR.txt");
+    double timestamp, prev = start_timestamp;
+    std::array<double, 3> c{0, 0, 0};
+    while (dr >> timestamp >> c[0] >> c[1]) {
+      const double dt = timestamp - prev;
+      prev = timestamp;
+      d.add_control(dt, {c[0] / dt, c[1] / dt, c[2] / dt});
+    }
+  }
+  {  // :79-94
+    std::ifstream td(dir + "/" + name + "/" + name + "_TD.txt");
+    if (!td) throw std::runtime_error("cannot open " + name + "_TD.txt");
+    double timestamp, antenna, id, range;
+    std::set<std::pair<std::size_t, std::size_t>> observed;
+    while (td >> timestamp >> antenna >> id >> range) {
+      const std::size_t fid = std::size_t(std::round(id));
+      const std::size_t ts = d.timestep_at(timestamp - start_timestamp);
+      if (observed.emplace(ts, fid).second) d.add_observation(ts, fid, range);
+    }
+  }
+  return d;
+}
+
+// ---------------------------------------------------------------------------
+// src/slam/slam_data.hpp:28-148
+struct slam_data {
+  using feature_observations = std::vector<std::pair<std::size_t, range_only_model>>;  // sorted by t
+  struct observation_info {
+    std::size_t id;
+    std::size_t index;  // position inside the feature's list
+  };
+  struct listener {
+    virtual void control(std::size_t, const velocity_slip_model&) {}
+    virtual void observation(std::size_t, const observation_info&) {}
+    virtual void timestep(std::size_t) {}
+    virtual void completed() {}
+    virtual ~listener() = default;
+  };
+
+  std::map<std::size_t, feature_observations> features;
+  std::vector<std::pair<std::size_t, observation_info>> observations;  // by t
+  std::vector<velocity_slip_model> controls;
+  std::vector<listener*> data_listeners;      // receive control/observation
+  std::vector<listener*> timestep_listeners;  // receive timestep/completed, in order
+
+  std::size_t current_timestep() const { return controls.size(); }
+  const velocity_slip_model& control(std::size_t t) const { return controls.at(t); }
+  const feature_observations& get_observations(std::size_t id) const { return features.at(id); }
+  bool feature_observed(std::size_t id) const { return features.count(id) != 0; }
+  const range_only_model& observation(const observation_info& o) const { return features.at(o.id)[o.index].second; }
+  std::pair<std::size_t, std::size_t> observations_at(std::size_t t) const {
+    auto lo = std::lower_bound(observations.begin(), observations.end(), t,
+                               [](const auto& o, std::size_t v) { return o.first < v; });
+    auto hi = std::upper_bound(observations.begin(), observations.end(), t,
+                               [](std::size_t v, const auto& o) { return v < o.first; });
+    return {std::size_t(lo - observations.begin()), std::size_t(hi - observations.begin())};
+  }
+  void add_listener(listener* l) {  // :144-147
+    timestep_listeners.push_back(l);
+    data_listeners.push_back(l);
+  }
+  void add_timestep_listener(listener* l) { timestep_listeners.push_back(l); }
+
+  // :153-162
+  void add_control(const velocity_slip_model& c) {
+    const std::size_t t = current_timestep();
+    controls.push_back(c);
+    for (auto* l : data_listeners) l->control(t, controls.back());
+  }
+  // :165-188
+  void add_observation(std::size_t id, const range_only_model& obs) {
+    const std::size_t t = current_timestep();
+    auto& list = features[id];
+    list.emplace_back(t, obs);
+    const observation_info info{id, list.size() - 1};
+    observations.emplace_back(t, info);
+    for (auto* l : data_listeners) l->observation(t, info);
+  }
+  void timestep(std::size_t t) {  // :90-94
+    for (auto* l : timestep_listeners) l->timestep(t);
+  }
+  void completed() {  // :96-99
+    for (auto* l : timestep_listeners) l->completed();
+  }
+  // :191-215
+  void add_dataset(const dataset& data, const velocity_slip_model::builder& cb, const range_only_model::builder& ob) {
+    auto add_observations = [&](std::size_t t) {
+      auto r = data.observations_at(t);
+      for (std::size_t i = r.first; i < r.second; ++i)
+        add_observation(data.observations[i].id, ob(data.observations[i].range));
+    };
+    add_observations(current_timestep());
+    timestep(current_timestep());
+    while (current_timestep() < data.current_timestep()) {
+      const std::size_t t = current_timestep();
+      add_control(cb(data.controls[t].data(), data.timedelta(t)));
+      add_observations(current_timestep());
+      timestep(current_timestep());
+    }
+    completed();
+  }
+};
+
+// src/slam/interfaces.hpp:100-124 -- the read interface of every back end.
+struct slam_result {
+  virtual std::size_t current_timestep() const = 0;
+  virtual pose get_initial_state() const { return pose(); }
+  virtual pose get_state(std::size_t t) const { return get_initial_state() + get_trajectory().accumulate(t); }
+  virtual position get_feature(std::size_t id) const { return get_feature_map().at(id); }
+  virtual const bitree<pose>& get_trajectory() const = 0;
+  virtual const std::map<std::size_t, position>& get_feature_map() const = 0;
+  virtual ~slam_result() = default;
+};
+
+// src/slam/slam_initialiser.hpp:21-50 (+ slam_result_impl.hpp)
+struct slam_initialiser : slam_data::listener, slam_result {
+  const slam_data* data;
+  random_source random;
+  bitree<pose> trajectory;
+  std::map<std::size_t, position> map;
+  slam_initialiser(const slam_data* d, std::uint32_t seed) : data(d), random(seed) {}
+  void control(std::size_t, const velocity_slip_model& c) override {  // :33-38
+    trajectory.push_back(c.proposal_initial_value(random));
+  }
+  void observation(std::size_t t, const slam_data::observation_info& o) override {  // :40-49
+    if (o.index == 0) {
+      const position init = data->observation(o).proposal_initial_value(random);
+      map[o.id] = get_state(t) + init;
+    }
+  }
+  std::size_t current_timestep() const override { return trajectory.size(); }
+  const bitree<pose>& get_trajectory() const override { return trajectory; }
+  const std::map<std::size_t, position>& get_feature_map() const override { return map; }
+};
+
+// ---------------------------------------------------------------------------
+// One record per MH step, for parity tests.
+struct step_record {
+  int kind;         // 0 = state edge, 1 = feature edge
+  std::size_t index;
+  double proposed[3];  // pose (x,y,th) or position (x,y,0)
+  double log_ratio;
+  int accepted;
+  double log_likelihood;  // chain LL after the step
+};
+
+// src/slam/mcmc_slam.hpp:37-223 and the member definitions below it.
+class mcmc_slam : public slam_data::listener, public slam_result {
+ public:
+  struct feature_estimate {  // :66-82
+    std::size_t id;
+    std::size_t parent_timestep;
+    position estimate;
+  };
+
+ private:
+  const slam_data* data;
+  slam_result* initialiser = nullptr;
+  random_source random;
+  bitree<pose> state_estimates;
+  bitree<double> state_weights;
+  std::vector<feature_estimate> feature_estimates;
+  bitree<double> feature_weights;
+  std::map<std::size_t, std::size_t> feature_index;
+  mutable std::map<std::size_t, position> map_estimate;
+  std::size_t next_timestep = 0;
+  double log_likelihood = 0;
+
+ public:
+  bool uniform_first = true;  // draw order inside range_only proposals, see range_only_model::propose
+  std::uint64_t units = 0;    // executions of the loop body :487-502
+  std::vector<step_record>* trace = nullptr;
+  unsigned steps_per_timestep = 0, end_steps = 0;  // the nested updater :200-222
+
+  mcmc_slam(const slam_data* d, std::uint32_t seed) : data(d), random(seed) {}  // :165-166
+  void set_initialiser(slam_result* init) { initialiser = init; }              // :175-177
+  double get_log_likelihood() const { return log_likelihood; }                 // :173
+  const std::vector<feature_estimate>& features() const { return feature_estimates; }
+  const bitree<double>& get_state_weights() const { return state_weights; }
+  const bitree<double>& get_feature_weights() const { return feature_weights; }
+  random_source& rng() { return random; }
+
+  static double edge_log_weight(double ell, double dim) { return std::log(dim) - ell / dim; }  // :160-162
+
+ private:
+  // :228-246
+  void add_state_edge() {
+    const velocity_slip_model& control = data->control(current_timestep());
+    const pose estimate = initialiser ? -initialiser->get_state(current_timestep()) +
+                                            initialiser->get_state(current_timestep() + 1)
+                                      : control.proposal_initial_value(random);
+    state_estimates.push_back(estimate);
+    state_weights.push_back(
+        std::exp(edge_log_weight(control.proposal_log_likelihood(estimate), velocity_slip_model::proposal_dim)));
+    log_likelihood += control.log_likelihood_of(estimate);
+  }
+  // :249-270
+  void add_feature_edge(const slam_data::observation_info& obs) {
+    const range_only_model& observation = data->observation(obs);
+    const position estimate = initialiser
+                                  ? -initialiser->get_state(current_timestep()) + initialiser->get_feature(obs.id)
+                                  : observation.proposal_initial_value(random);
+    feature_estimates.push_back({obs.id, current_timestep(), estimate});
+    feature_weights.push_back(
+        std::exp(edge_log_weight(observation.proposal_log_likelihood(estimate), range_only_model::proposal_dim)));
+    log_likelihood += observation.log_likelihood_of(estimate);
+  }
+
+  // :477-505.  [lo,hi) indexes the feature's time-sorted observation list.
+  double obs_likelihood_ratio(const feature_estimate& feature, std::size_t obs_timestep, std::size_t lo,
+                              std::size_t hi, position new_obs) {
+    const auto& list = data->get_observations(feature.id);
+    double log_ratio = 0.0;
+    position old_obs = feature.estimate;
+    old_obs = state_estimates.accumulate(obs_timestep, feature.parent_timestep) + old_obs;
+    for (std::size_t i = lo; i < hi; ++i) {
+      const auto& obs = list[i];
+      const pose state_change = state_estimates.accumulate(obs.first, obs_timestep);
+      new_obs = state_change + new_obs;
+      old_obs = state_change + old_obs;
+      const double new_ll = obs.second.log_likelihood_of(new_obs);
+      const double old_ll = obs.second.log_likelihood_of(old_obs);
+      obs_timestep = obs.first;
+      log_ratio += new_ll - old_ll;
+      ++units;
+    }
+    return log_ratio;
+  }
+  // :433-466
+  double state_edge_log_likelihood_ratio(std::size_t t, const pose& proposed) {
+    const velocity_slip_model& dist = data->control(t);
+    double log_ratio = +dist.log_likelihood_of(proposed) - dist.log_likelihood_of(state_estimates.get(t));
+    for (const auto& f : feature_estimates) {
+      const auto& list = data->get_observations(f.id);
+      const std::size_t middle =
+          std::upper_bound(list.begin(), list.end(), t, [](std::size_t v, const auto& o) { return v < o.first; }) -
+          list.begin();
+      if (t < f.parent_timestep) {
+        const pose delta = state_estimates.accumulate(t + 1, f.parent_timestep);
+        log_ratio += obs_likelihood_ratio(f, t, 0, middle, (proposed + delta) + f.estimate);
+      } else {
+        const pose delta = state_estimates.accumulate(t, f.parent_timestep);
+        log_ratio += obs_likelihood_ratio(f, t + 1, middle, list.size(), (-proposed + delta) + f.estimate);
+      }
+    }
+    return log_ratio;
+  }
+  // :469-474
+  double feature_edge_log_likelihood_ratio(std::size_t fi, const position& proposed) {
+    const feature_estimate& f = feature_estimates[fi];
+    return obs_likelihood_ratio(f, f.parent_timestep, 0, data->get_observations(f.id).size(), proposed);
+  }
+
+  // :372-418, state-edge instance
+  bool update_state_edge(std::size_t t, bool use_edge_weight) {
+    const velocity_slip_model& dist = data->control(t);
+    const pose proposed = dist.propose(random);
+    const double new_pll = dist.proposal_log_likelihood(proposed);
+    const double old_pll = dist.proposal_log_likelihood(state_estimates.get(t));
+    const double proposal_log_ratio = new_pll - old_pll;
+    const double log_ratio = state_edge_log_likelihood_ratio(t, proposed);
+    const double new_log_weight = edge_log_weight(new_pll, velocity_slip_model::proposal_dim);
+    const double new_weight = std::exp(new_log_weight);
+    double normaliser = 1.0;
+    double accept_log_ratio = log_ratio - proposal_log_ratio;
+    if (use_edge_weight) {
+      const double old_log_weight = edge_log_weight(old_pll, velocity_slip_model::proposal_dim);
+      const double old_weight = std::exp(old_log_weight);
+      const double weight_sum = state_weights.accumulate() + feature_weights.accumulate();
+      normaliser += (new_weight - old_weight) / weight_sum;
+      accept_log_ratio += new_log_weight - old_log_weight;
+    }
+    const bool accept = normaliser * random.uniform() < std::exp(accept_log_ratio);
+    if (accept) {
+      state_estimates.set(t, proposed);
+      state_weights.set(t, new_weight);
+      log_likelihood += log_ratio;
+      map_estimate.clear();
+    }
+    if (trace) trace->push_back({0, t, {proposed.x, proposed.y, proposed.th}, log_ratio, accept, log_likelihood});
+    return accept;
+  }
+  // :372-418, feature-edge instance (distribution = the observation at the
+  // parent timestep, :108-112)
+  bool update_feature_edge(std::size_t fi, bool use_edge_weight) {
+    const feature_estimate& f = feature_estimates[fi];
+    const auto& list = data->get_observations(f.id);
+    auto it = std::lower_bound(list.begin(), list.end(), f.parent_timestep,
+                               [](const auto& o, std::size_t v) { return o.first < v; });
+    if (it == list.end() || it->first != f.parent_timestep) throw std::out_of_range("feature parent not observed");
+    const range_only_model& dist = it->second;
+    const position proposed = dist.propose(random, uniform_first);
+    const double new_pll = dist.proposal_log_likelihood(proposed);
+    const double old_pll = dist.proposal_log_likelihood(f.estimate);
+    const double proposal_log_ratio = new_pll - old_pll;
+    const double log_ratio = feature_edge_log_likelihood_ratio(fi, proposed);
+    const double new_log_weight = edge_log_weight(new_pll, range_only_model::proposal_dim);
+    const double new_weight = std::exp(new_log_weight);
+    double normaliser = 1.0;
+    double accept_log_ratio = log_ratio - proposal_log_ratio;
+    if (use_edge_weight) {
+      const double old_log_weight = edge_log_weight(old_pll, range_only_model::proposal_dim);
+      const double old_weight = std::exp(old_log_weight);
+      const double weight_sum = state_weights.accumulate() + feature_weights.accumulate();
+      normaliser += (new_weight - old_weight) / weight_sum;
+      accept_log_ratio += new_log_weight - old_log_weight;
+    }
+    const bool accept = normaliser * random.uniform() < std::exp(accept_log_ratio);
+    if (accept) {
+      feature_estimates[fi].estimate = proposed;
+      feature_weights.set(fi, new_weight);
+      log_likelihood += log_ratio;
+      map_estimate.clear();
+    }
+    if (trace) trace->push_back({1, fi, {proposed.x, proposed.y, 0.0}, log_ratio, accept, log_likelihood});
+    return accept;
+  }
+
+ public:
+  // :273-336
+  void timestep(std::size_t timestep) override {
+    grow(timestep);
+    for (unsigned i = 0; i < steps_per_timestep; ++i) update();  // updater::timestep :213-216
+  }
+  void completed() override {  // updater::completed :218-221
+    for (unsigned i = 0; i < end_steps; ++i) update();
+  }
+  void grow(std::size_t timestep) {
+    while (next_timestep <= timestep) {
+      if (next_timestep > 0) add_state_edge();
+      const auto r = data->observations_at(next_timestep);
+      for (std::size_t oi = r.first; oi < r.second; ++oi) {
+        const slam_data::observation_info& obs = data->observations[oi].second;
+        const auto insertion = feature_index.emplace(obs.id, feature_estimates.size());
+        if (insertion.second) {
+          add_feature_edge(obs);
+          map_estimate.clear();
+        } else {
+          const std::size_t t = next_timestep;
+          const range_only_model& observation = data->observation(obs);
+          const std::size_t fi = insertion.first->second;
+          feature_estimate& f = feature_estimates[fi];
+          const pose delta = state_estimates.accumulate(t, f.parent_timestep);
+          const position estimate = delta + f.estimate;
+          log_likelihood += observation.log_likelihood_of(estimate);
+          const auto& list = data->get_observations(f.id);
+          auto pit = std::lower_bound(list.begin(), list.end(), f.parent_timestep,
+                                      [](const auto& o, std::size_t v) { return o.first < v; });
+          if (observation.more_accurate_than(pit->second)) {  // :310-311
+            f.parent_timestep = t;
+            f.estimate = estimate;
+            if (!update_feature_edge(fi, false)) {  // :320-323
+              feature_weights.set(fi, std::exp(edge_log_weight(observation.proposal_log_likelihood(estimate),
+                                                               range_only_model::proposal_dim)));
+            }
+          }
+        }
+      }
+      ++next_timestep;
+    }
+  }
+
+  // :340-368
+  bool update() {
+    const double state_weight = state_weights.accumulate();
+    const double feature_weight = feature_weights.accumulate();
+    if (state_weight == 0 && feature_weight == 0) return false;
+    if ((state_weight + feature_weight) * random.uniform() < state_weight) {
+      std::size_t t;
+      do {
+        t = state_weights.binary_search(state_weight * random.uniform());
+      } while (t >= current_timestep() && ((std::cerr << "stuck in timestep select loop\n"), true));
+      return update_state_edge(t, true);
+    } else {
+      std::size_t index;
+      do {
+        index = feature_weights.binary_search(feature_weight * random.uniform());
+      } while (index >= feature_estimates.size() && ((std::cerr << "stuck in landmark select loop\n"), true));
+      return update_feature_edge(index, true);
+    }
+  }
+
+  // Evaluate (without side effects on the chain) the log-likelihood ratio of a
+  // given proposal -- the quantity :385 feeds into the accept test.
+  double eval_state_edge(std::size_t t, const pose& proposed) { return state_edge_log_likelihood_ratio(t, proposed); }
+  double eval_feature_edge(std::size_t fi, const position& proposed) {
+    return feature_edge_log_likelihood_ratio(fi, proposed);
+  }
+
+  std::size_t current_timestep() const override { return state_estimates.size(); }  // :185-187
+  position get_feature(std::size_t id) const override {                              // :189-192
+    const feature_estimate& f = feature_estimates[feature_index.at(id)];
+    return get_state(f.parent_timestep) + f.estimate;
+  }
+  const bitree<pose>& get_trajectory() const override { return state_estimates; }  // :194-196
+  const std::map<std::size_t, position>& get_feature_map() const override {        // :508-525
+    if (map_estimate.size() != feature_estimates.size()) {
+      map_estimate.clear();
+      for (const auto& id_index : feature_index) {
+        const feature_estimate& f = feature_estimates[id_index.second];
+        map_estimate.emplace_hint(map_estimate.end(), id_index.first, get_state(f.parent_timestep) + f.estimate);
+      }
+    }
+    return map_estimate;
+  }
+};
+
+// src/slam/slam_likelihood.hpp:26-58 -- full (non-incremental) log likelihood.
+inline double slam_log_likelihood(const slam_data& data, const slam_result& estimate) {
+  double ll = 0;
+  const auto& trajectory = estimate.get_trajectory();
+  for (std::size_t t = 0; t < trajectory.size(); ++t) ll += data.control(t).log_likelihood_of(trajectory[t]);
+  const pose initial_state = estimate.get_initial_state();
+  for (const auto& id_feature : estimate.get_feature_map()) {
+    const std::size_t id = id_feature.first;
+    if (!data.feature_observed(id)) continue;
+    position feature = -initial_state + id_feature.second;
+    std::size_t timestep = 0;
+    for (const auto& obs : data.get_observations(id)) {
+      feature = trajectory.accumulate(obs.first, timestep) + feature;
+      timestep = obs.first;
+      ll += obs.second.log_likelihood_of(feature);
+    }
+  }
+  return ll;
+}
+
+// src/slam/multi_mcmc.hpp:34-169
+class multi_mcmc : public slam_data::listener {
+ public:
+  std::vector<std::unique_ptr<mcmc_slam>> chains;
+  mcmc_slam* max_likelihood;
+  unsigned num_updates = 0, num_accepted = 0;
+  unsigned end_steps = 0;
+  std::vector<std::array<double, 3>> report;  // the lines of multi-mcmc-report.txt :135-137
+
+  multi_mcmc(const slam_data* data, unsigned num_chains, std::uint32_t seed) {  // :155-169
+    random_source random(seed);
+    while (num_chains--) chains.push_back(std::make_unique<mcmc_slam>(data, random()));
+    max_likelihood = chains.front().get();
+  }
+  void timestep(std::size_t t) override {  // :77-79
+    for (auto& c : chains) c->grow(t);
+  }
+  void update(unsigned count) {  // :106-119
+    for (auto& c : chains) {
+      for (unsigned i = 0; i < count; ++i) {
+        if (c->update()) ++num_accepted;
+        ++num_updates;
+      }
+      if (c->get_log_likelihood() > max_likelihood->get_log_likelihood()) max_likelihood = c.get();
+    }
+  }
+  void completed() override {  // :122-139
+    unsigned remaining = end_steps;
+    const unsigned report_every = 100;
+    while (remaining > 0) {
+      if (remaining > report_every) {
+        update(report_every);
+        remaining -= report_every;
+      } else {
+        update(remaining);
+        remaining = 0;
+      }
+      report.push_back({double(num_updates) / chains.size(), double(num_accepted) / chains.size(),
+                        max_likelihood->get_log_likelihood()});
+    }
+  }
+};
+
+// src/main.cpp:133-147 -- module seeds are six successive engine draws, made
+// unconditionally, in this order.
+struct module_seeds {
+  std::uint32_t sim, init, mcmc_slam, hmc, fastslam, multi_mcmc;
+  explicit module_seeds(std::uint32_t seed) {
+    random_source random(seed);
+    sim = random();
+    init = random();
+    mcmc_slam = random();
+    hmc = random();
+    fastslam = random();
+    multi_mcmc = random();
+  }
+};
+
+}  // namespace oracle
+
+#endif  // SLAM_ORACLE_HPP
