@@ -1,0 +1,8 @@
+#!/bin/bash
+# Builds the GPU library (gfx950) and the CPU oracle used by the tests.
+set -e
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+$HIPCC -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared -std=c++17 \
+  -Wall -Wno-unused-function -o slam_amd/libmcmcgpu.so slam_amd/csrc/mcmcgpu.hip
+make -s -C oracle

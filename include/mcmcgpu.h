@@ -1,0 +1,190 @@
+/*
+ * mcmcgpu -- MI355X (gfx950) implementation of the MCMC-SLAM proposal
+ * evaluation path, behind a plain C ABI.
+ *
+ * The reference (tree: roshanshariff/slam) has no FFI: the seam is the C++
+ * class slam::mcmc_slam<velocity_slip_model, range_only_model>
+ * (src/slam/mcmc_slam.hpp:37-223, instantiated at src/slam/mcmc_slam.cpp:11).
+ * A host-side class with the same public surface (slam_amd/host/) keeps its
+ * whole sampler state on the GPU behind one of these handles; every entry
+ * point below names the reference member it stands in for.
+ *
+ * Conventions: every function returns 0 on success and a negative
+ * mcmcgpu_status on failure; mcmcgpu_last_error() gives the message.  All
+ * pointers are HOST pointers unless the parameter name starts with `dev_`.
+ * All floating point is IEEE binary64.  A handle is not thread-safe; all work
+ * of a handle is ordered on one HIP stream.
+ */
+#ifndef MCMCGPU_H
+#define MCMCGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mcmcgpu_ctx* mcmcgpu_handle;
+
+enum mcmcgpu_status {
+  MCMCGPU_OK = 0,
+  MCMCGPU_ERR_ARGUMENT = -1,
+  MCMCGPU_ERR_CAPACITY = -2,
+  MCMCGPU_ERR_HIP = -3,
+  MCMCGPU_ERR_STATE = -4,
+  MCMCGPU_ERR_DEVICE_FAULT = -5 /* a chain reported an internal error flag */
+};
+
+enum mcmcgpu_edge_kind { MCMCGPU_STATE_EDGE = 0, MCMCGPU_FEATURE_EDGE = 1 };
+
+typedef struct mcmcgpu_config {
+  int32_t device;             /* HIP device ordinal */
+  uint32_t max_chains;        /* C: independent chains held by this handle */
+  uint32_t max_timesteps;     /* capacity for controls (state edges) */
+  uint32_t max_features;      /* capacity for landmarks */
+  uint32_t max_observations;  /* capacity for range readings */
+  uint32_t block_shift;       /* log2 of poses per cumulative-pose block; 0 -> 8 */
+  uint32_t threads_per_chain; /* workgroup size; 0 -> 256; multiple of 64, <= 1024 */
+  /* Order of the two draws inside a landmark proposal.  The reference leaves it
+   * unsequenced (src/planar_robot/range_bearing_model.hpp:155-159): 1 = uniform
+   * then normal (what g++ emits), 0 = normal then uniform (clang). */
+  uint32_t feature_uniform_first;
+  uint32_t trace_capacity;    /* MH steps recorded per chain (0 = none) */
+  void* stream;               /* hipStream_t to run on; NULL = a stream of its own */
+} mcmcgpu_config;
+
+/* One Metropolis-Hastings step as recorded when trace_capacity > 0. */
+typedef struct mcmcgpu_step_record {
+  int32_t kind;       /* mcmcgpu_edge_kind */
+  int32_t accepted;   /* 0 / 1 */
+  uint64_t index;     /* timestep of the state edge, or landmark index */
+  double proposed[3]; /* pose (x, y, bearing) or position (x, y, 0) */
+  double log_ratio;   /* value of edge_log_likelihood_ratio, mcmc_slam.hpp:385 */
+  double log_likelihood; /* chain log likelihood after the step */
+} mcmcgpu_step_record;
+
+/* Per-chain summary, the unit of the multi-GPU all-gather (the serial arg-max
+ * of src/slam/multi_mcmc.hpp:109-118 becomes a reduction over these). */
+typedef struct mcmcgpu_chain_summary {
+  double log_likelihood;
+  uint32_t updates;
+  uint32_t accepts;
+} mcmcgpu_chain_summary;
+
+const char* mcmcgpu_last_error(mcmcgpu_handle h); /* h may be NULL: last create error */
+
+/* Allocates every device buffer for the stated capacities; nothing else
+ * allocates later.  Stands in for constructing mcmc_slam objects
+ * (mcmc_slam.hpp:165-166) and for multi_mcmc's chain vector (multi_mcmc.hpp:164-166). */
+int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out);
+void mcmcgpu_destroy(mcmcgpu_handle h);
+
+/* The data the sampler reads -- the contents of slam_data
+ * (src/slam/slam_data.hpp:28-148): one normal model per control
+ * (mean/stddev, 3 doubles each, src/planar_robot/velocity_model.hpp:176-180)
+ * and one per range reading (range_bearing_model.hpp:192-194), readings in
+ * ARRIVAL order (non-decreasing timestep, 0..T).  obs_feature holds dense
+ * landmark indices numbered in order of first appearance (the index into
+ * mcmc_slam::feature_estimates, mcmc_slam.hpp:125-129).  May be called again
+ * with a longer problem whose prefix is unchanged (online growth). */
+int mcmcgpu_upload_problem(mcmcgpu_handle h, uint32_t T, const double* ctrl_mean, const double* ctrl_stddev,
+                           uint32_t N, const uint32_t* obs_timestep, const uint32_t* obs_feature,
+                           const double* obs_mean, const double* obs_stddev, uint32_t F);
+
+/* Creates C empty chains (timestep 0 not yet processed), chain i seeded like
+ * random_source(seeds[i]) (src/utility/random.hpp:24).  init_uniforms, when
+ * not NULL, holds one uniform per landmark: the draws a slam_initialiser
+ * (src/slam/slam_initialiser.hpp:40-49) would have made; landmarks are then
+ * placed from those instead of the chain's own generator, which is what
+ * mcmc_slam::set_initialiser changes (mcmc_slam.hpp:255-259). */
+int mcmcgpu_init_chains(mcmcgpu_handle h, uint32_t C, const uint32_t* seeds, const double* init_uniforms,
+                        uint32_t n_init_uniforms);
+
+/* The whole of slam_data::add_dataset as the sampler sees it
+ * (slam_data.hpp:191-215 driving mcmc_slam::timestep, mcmc_slam.hpp:272-336,
+ * and mcmc_slam::updater, :200-222): for every not yet processed timestep up
+ * to `upto` (inclusive) grow the graph, then do `steps_per_timestep` updates;
+ * afterwards `end_steps` more.  mcmcgpu_grow == advance(upto, 0, 0);
+ * mcmcgpu_run == advance(current, 0, steps) == steps x mcmc_slam::update()
+ * (mcmc_slam.hpp:339-368) on every chain.  Asynchronous on the stream. */
+int mcmcgpu_advance(mcmcgpu_handle h, uint32_t upto, uint32_t steps_per_timestep, uint32_t end_steps);
+int mcmcgpu_grow(mcmcgpu_handle h, uint32_t upto);
+int mcmcgpu_run(mcmcgpu_handle h, uint32_t steps);
+
+/* edge_log_likelihood_ratio (mcmc_slam.hpp:432-474) for one given proposal on
+ * one chain, without changing the chain.  For a state edge the value includes
+ * the control term (:436-438). */
+int mcmcgpu_eval_llr(mcmcgpu_handle h, uint32_t chain, int kind, uint32_t index, const double proposed[3],
+                     double* out);
+
+/* The accept branch of mcmc_slam::update(EdgeType&&, bool), :409-413: store
+ * the proposal, set the edge weight, add log_ratio to the chain's likelihood. */
+int mcmcgpu_commit(mcmcgpu_handle h, uint32_t chain, int kind, uint32_t index, const double proposed[3],
+                   double new_weight, double log_ratio);
+
+/* Rebuilds every chain's cumulative poses from its relative poses with the
+ * SE(2) prefix scan (replaces re-deriving bitree<pose> nodes,
+ * src/utility/bitree.hpp:182-184); removes accumulated rounding drift. */
+int mcmcgpu_rebuild(mcmcgpu_handle h);
+
+/* get_log_likelihood (mcmc_slam.hpp:173) for chains [0, C). */
+int mcmcgpu_get_log_likelihood(mcmcgpu_handle h, double* out);
+/* slam_log_likelihood (src/slam/slam_likelihood.hpp:26-58) recomputed from
+ * scratch on the device for every chain. */
+int mcmcgpu_full_log_likelihood(mcmcgpu_handle h, double* out);
+
+/* Chain read-out -- what get_trajectory / get_state / get_feature /
+ * get_feature_map return (mcmc_slam.hpp:189-198, 507-525).  Any pointer may
+ * be NULL.  rel_poses: [T][3] relative pose per state edge; cum_poses:
+ * [T+1][3] = get_state(k); feat_parent: [F] parent timestep; feat_estimate:
+ * [F][2] parent-relative estimate; feat_world: [F][2] = get_feature();
+ * state_weights [T], feat_weights [F]: edge weights. */
+int mcmcgpu_get_state(mcmcgpu_handle h, uint32_t chain, double* rel_poses, double* cum_poses,
+                      uint32_t* feat_parent, double* feat_estimate, double* feat_world, double* state_weights,
+                      double* feat_weights);
+/* Current sizes: timesteps grown (state edges), landmarks known, chains. */
+int mcmcgpu_get_dims(mcmcgpu_handle h, uint32_t* timesteps, uint32_t* features, uint32_t* chains);
+
+/* Counters since init: updates, accepted updates and evaluated observations
+ * (executions of the loop body mcmc_slam.hpp:487-502), per chain. */
+int mcmcgpu_get_counters(mcmcgpu_handle h, uint64_t* updates, uint64_t* accepts, uint64_t* units);
+
+/* Recorded steps of one chain (trace_capacity > 0); *count = number returned. */
+int mcmcgpu_get_trace(mcmcgpu_handle h, uint32_t chain, mcmcgpu_step_record* out, uint32_t capacity,
+                      uint32_t* count);
+
+/* Writes C mcmcgpu_chain_summary records to DEVICE memory (stream-ordered),
+ * ready to be all-gathered across GPUs. */
+int mcmcgpu_write_summaries(mcmcgpu_handle h, void* dev_out);
+/* Packs one chain's state (relative poses [T][3], then feat estimates [F][2])
+ * as doubles into DEVICE memory, for a broadcast of the best chain;
+ * mcmcgpu_import_state is the receiving side. */
+int mcmcgpu_export_state(mcmcgpu_handle h, uint32_t chain, void* dev_out);
+int mcmcgpu_import_state(mcmcgpu_handle h, uint32_t chain, const void* dev_in, double log_likelihood);
+
+/* Blocks until all work queued on the handle's stream is done and reports a
+ * device-side error flag if any chain set one. */
+int mcmcgpu_sync(mcmcgpu_handle h);
+/* Average device duration (ms) of the advance kernel launches timed with HIP
+ * events since the last call (reset on read), and how many there were. */
+int mcmcgpu_kernel_time(mcmcgpu_handle h, double* avg_ms, uint32_t* launches);
+
+/* Host helpers for seeding, same generator as the chains: n successive 32-bit
+ * draws of random_source(seed) -- the chain seeds of multi_mcmc
+ * (src/slam/multi_mcmc.hpp:160-166) and the module seeds of src/main.cpp:133-147
+ * -- and n successive uniform() draws (what a slam_initialiser consumes, one
+ * per new landmark, src/slam/slam_initialiser.hpp:44-47). */
+void mcmcgpu_seed_sequence(uint32_t seed, uint32_t n, uint32_t* out);
+void mcmcgpu_uniform_sequence(uint32_t seed, uint32_t n, double* out);
+
+/* Test hook for the scan building block: inclusive prefix "sums" of n affine
+ * maps x -> a + b*x (mod p) under composition, computed by the same wavefront
+ * scan template that builds cumulative poses (exact integer arithmetic; the
+ * group of the reference's own tree test, test/bitree.cpp:36-54). */
+int mcmcgpu_selftest_scan(int32_t device, uint32_t n, int32_t p, const int32_t* a, const int32_t* b,
+                          int32_t* out_a, int32_t* out_b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCMCGPU_H */

@@ -4,6 +4,7 @@
 // benchmark's cpu_baseline leg can drive the restated reference algorithm.
 // Not part of the shipped library; see the header of slam_oracle.hpp.
 #include <cstring>
+#include <deque>
 #include <random>
 #include <thread>
 
@@ -26,7 +27,7 @@ struct world {
   slam_data data;
   std::unique_ptr<slam_initialiser> init;
   std::vector<std::unique_ptr<mcmc_slam>> chains;
-  std::vector<std::vector<step_record>> traces;
+  std::deque<std::vector<step_record>> traces;  // deque: chains keep pointers into it
   std::size_t replayed_upto = 0;  // next timestep to feed
   bool started = false;
   std::size_t next_obs = 0;
@@ -190,7 +191,12 @@ int ora_world_replay(void* p, std::uint32_t upto, int finish) {
 int ora_chain_update(void* p, int chain, std::uint32_t nsteps) {
   world& w = *static_cast<world*>(p);
   int accepted = 0;
-  for (std::uint32_t i = 0; i < nsteps; ++i) accepted += w.chains[chain]->update() ? 1 : 0;
+  try {
+    for (std::uint32_t i = 0; i < nsteps; ++i) accepted += w.chains[chain]->update() ? 1 : 0;
+  } catch (const std::exception& e) {
+    w.error = e.what();
+    return -1;
+  }
   return accepted;
 }
 
@@ -206,8 +212,11 @@ std::uint64_t ora_world_update_all(void* p, std::uint32_t nsteps, std::uint32_t 
   std::vector<std::thread> pool;
   for (std::uint32_t k = 0; k < nthreads; ++k)
     pool.emplace_back([&, k]() {
-      for (std::size_t c = k; c < n; c += nthreads)
-        for (std::uint32_t i = 0; i < nsteps; ++i) w.chains[c]->update();
+      try {
+        for (std::size_t c = k; c < n; c += nthreads)
+          for (std::uint32_t i = 0; i < nsteps; ++i) w.chains[c]->update();
+      } catch (const std::exception&) {
+      }
     });
   for (auto& t : pool) t.join();
   std::uint64_t after = 0;

@@ -837,6 +837,13 @@ class mcmc_slam : public slam_data::listener, public slam_result {
     }
   }
 
+  // The reference retries forever (printing "stuck in ... select loop") when the
+  // searched index is out of range, :350-354,361-364.  That can only end if the
+  // weight totals are finite; a weight that overflowed to infinity makes the
+  // reference hang.  The oracle gives up instead of hanging the test suite.
+  static void check_retry(unsigned retries) {
+    if (retries > 100000) throw std::runtime_error("edge selection does not terminate (non-finite edge weight)");
+  }
   // :340-368
   bool update() {
     const double state_weight = state_weights.accumulate();
@@ -844,15 +851,19 @@ class mcmc_slam : public slam_data::listener, public slam_result {
     if (state_weight == 0 && feature_weight == 0) return false;
     if ((state_weight + feature_weight) * random.uniform() < state_weight) {
       std::size_t t;
+      unsigned retries = 0;
       do {
         t = state_weights.binary_search(state_weight * random.uniform());
-      } while (t >= current_timestep() && ((std::cerr << "stuck in timestep select loop\n"), true));
+        check_retry(++retries);
+      } while (t >= current_timestep());
       return update_state_edge(t, true);
     } else {
       std::size_t index;
+      unsigned retries = 0;
       do {
         index = feature_weights.binary_search(feature_weight * random.uniform());
-      } while (index >= feature_estimates.size() && ((std::cerr << "stuck in landmark select loop\n"), true));
+        check_retry(++retries);
+      } while (index >= feature_estimates.size());
       return update_feature_edge(index, true);
     }
   }

@@ -1,0 +1,270 @@
+"""ctypes binding of the C ABI in include/mcmcgpu.h (libmcmcgpu.so, gfx950).
+
+Plumbing only: numpy arrays in, numpy arrays out.  There is no CPU fallback --
+if the library is missing or no MI355X is visible the calls raise.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmcmcgpu.so")
+
+STATE_EDGE = 0
+FEATURE_EDGE = 1
+
+
+class Config(ctypes.Structure):
+    _fields_ = [
+        ("device", ctypes.c_int32),
+        ("max_chains", ctypes.c_uint32),
+        ("max_timesteps", ctypes.c_uint32),
+        ("max_features", ctypes.c_uint32),
+        ("max_observations", ctypes.c_uint32),
+        ("block_shift", ctypes.c_uint32),
+        ("threads_per_chain", ctypes.c_uint32),
+        ("feature_uniform_first", ctypes.c_uint32),
+        ("trace_capacity", ctypes.c_uint32),
+        ("stream", ctypes.c_void_p),
+    ]
+
+
+STEP_RECORD = np.dtype(
+    [
+        ("kind", np.int32),
+        ("accepted", np.int32),
+        ("index", np.uint64),
+        ("proposed", np.float64, (3,)),
+        ("log_ratio", np.float64),
+        ("log_likelihood", np.float64),
+    ],
+    align=True,
+)
+
+CHAIN_SUMMARY = np.dtype([("log_likelihood", np.float64), ("updates", np.uint32), ("accepts", np.uint32)], align=True)
+
+# Every symbol include/mcmcgpu.h declares (the header is the source of truth;
+# tests/test_abi.py checks the two lists against each other).
+EXPORTS = [
+    "mcmcgpu_last_error",
+    "mcmcgpu_create",
+    "mcmcgpu_destroy",
+    "mcmcgpu_upload_problem",
+    "mcmcgpu_init_chains",
+    "mcmcgpu_advance",
+    "mcmcgpu_grow",
+    "mcmcgpu_run",
+    "mcmcgpu_eval_llr",
+    "mcmcgpu_commit",
+    "mcmcgpu_rebuild",
+    "mcmcgpu_get_log_likelihood",
+    "mcmcgpu_full_log_likelihood",
+    "mcmcgpu_get_state",
+    "mcmcgpu_get_dims",
+    "mcmcgpu_get_counters",
+    "mcmcgpu_get_trace",
+    "mcmcgpu_write_summaries",
+    "mcmcgpu_export_state",
+    "mcmcgpu_import_state",
+    "mcmcgpu_sync",
+    "mcmcgpu_kernel_time",
+    "mcmcgpu_seed_sequence",
+    "mcmcgpu_uniform_sequence",
+    "mcmcgpu_selftest_scan",
+]
+
+_lib = None
+
+
+def load_library():
+    """Loads libmcmcgpu.so (built by build.sh / __graft_entry__.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(f"{_LIB_PATH} is missing: run ./build.sh (hipcc, gfx950) first")
+        lib = ctypes.CDLL(_LIB_PATH)
+        lib.mcmcgpu_last_error.restype = ctypes.c_char_p
+        lib.mcmcgpu_last_error.argtypes = [ctypes.c_void_p]
+        lib.mcmcgpu_destroy.restype = None
+        lib.mcmcgpu_seed_sequence.restype = None
+        lib.mcmcgpu_uniform_sequence.restype = None
+        _lib = lib
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def seed_sequence(seed, n):
+    out = np.empty(n, dtype=np.uint32)
+    load_library().mcmcgpu_seed_sequence(ctypes.c_uint32(seed), ctypes.c_uint32(n), _ptr(out))
+    return out
+
+
+def uniform_sequence(seed, n):
+    out = np.empty(n, dtype=np.float64)
+    load_library().mcmcgpu_uniform_sequence(ctypes.c_uint32(seed), ctypes.c_uint32(n), _ptr(out))
+    return out
+
+
+def selftest_scan(a, b, p, device=0):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    b = np.ascontiguousarray(b, dtype=np.int32)
+    oa = np.empty_like(a)
+    ob = np.empty_like(b)
+    lib = load_library()
+    rc = lib.mcmcgpu_selftest_scan(ctypes.c_int32(device), ctypes.c_uint32(a.size), ctypes.c_int32(p), _ptr(a), _ptr(b),
+                                   _ptr(oa), _ptr(ob))
+    if rc != 0:
+        raise RuntimeError(f"mcmcgpu_selftest_scan failed ({rc}): {lib.mcmcgpu_last_error(None).decode()}")
+    return oa, ob
+
+
+class McmcGpu:
+    """One handle = C chains on one GPU."""
+
+    def __init__(self, max_chains, max_timesteps, max_features, max_observations, device=0, block_shift=0,
+                 threads_per_chain=0, feature_uniform_first=True, trace_capacity=0, stream=None):
+        self.lib = load_library()
+        cfg = Config(device, max_chains, max_timesteps, max_features, max_observations, block_shift, threads_per_chain,
+                     1 if feature_uniform_first else 0, trace_capacity, stream)
+        self.h = ctypes.c_void_p()
+        rc = self.lib.mcmcgpu_create(ctypes.byref(cfg), ctypes.byref(self.h))
+        if rc != 0:
+            raise RuntimeError(f"mcmcgpu_create failed ({rc}): {self.lib.mcmcgpu_last_error(None).decode()}")
+        self.trace_capacity = trace_capacity
+        self.chains = 0
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc}): {self.lib.mcmcgpu_last_error(self.h).decode()}")
+
+    def close(self):
+        if self.h:
+            self.lib.mcmcgpu_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload_problem(self, ctrl_mean, ctrl_std, obs_t, obs_f, obs_mean, obs_std, F):
+        cm = np.ascontiguousarray(ctrl_mean, dtype=np.float64).reshape(-1, 3)
+        cs = np.ascontiguousarray(ctrl_std, dtype=np.float64).reshape(-1, 3)
+        ot = np.ascontiguousarray(obs_t, dtype=np.uint32)
+        of = np.ascontiguousarray(obs_f, dtype=np.uint32)
+        om = np.ascontiguousarray(obs_mean, dtype=np.float64)
+        os_ = np.ascontiguousarray(obs_std, dtype=np.float64)
+        self._check(
+            self.lib.mcmcgpu_upload_problem(self.h, ctypes.c_uint32(cm.shape[0]), _ptr(cm), _ptr(cs),
+                                            ctypes.c_uint32(ot.size), _ptr(ot), _ptr(of), _ptr(om), _ptr(os_),
+                                            ctypes.c_uint32(F)), "mcmcgpu_upload_problem")
+
+    def init_chains(self, seeds, init_uniforms=None):
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+        iu = None if init_uniforms is None else np.ascontiguousarray(init_uniforms, dtype=np.float64)
+        self._check(
+            self.lib.mcmcgpu_init_chains(self.h, ctypes.c_uint32(seeds.size), _ptr(seeds), _ptr(iu),
+                                         ctypes.c_uint32(0 if iu is None else iu.size)), "mcmcgpu_init_chains")
+        self.chains = int(seeds.size)
+
+    def advance(self, upto, steps_per_timestep=0, end_steps=0):
+        self._check(
+            self.lib.mcmcgpu_advance(self.h, ctypes.c_uint32(upto), ctypes.c_uint32(steps_per_timestep),
+                                     ctypes.c_uint32(end_steps)), "mcmcgpu_advance")
+
+    def grow(self, upto):
+        self._check(self.lib.mcmcgpu_grow(self.h, ctypes.c_uint32(upto)), "mcmcgpu_grow")
+
+    def run(self, steps):
+        self._check(self.lib.mcmcgpu_run(self.h, ctypes.c_uint32(steps)), "mcmcgpu_run")
+
+    def eval_llr(self, chain, kind, index, proposed):
+        q = np.zeros(3, dtype=np.float64)
+        q[:len(proposed)] = proposed
+        out = ctypes.c_double()
+        self._check(
+            self.lib.mcmcgpu_eval_llr(self.h, ctypes.c_uint32(chain), ctypes.c_int(kind), ctypes.c_uint32(index),
+                                      _ptr(q), ctypes.byref(out)), "mcmcgpu_eval_llr")
+        return out.value
+
+    def commit(self, chain, kind, index, proposed, new_weight, log_ratio):
+        q = np.zeros(3, dtype=np.float64)
+        q[:len(proposed)] = proposed
+        self._check(
+            self.lib.mcmcgpu_commit(self.h, ctypes.c_uint32(chain), ctypes.c_int(kind), ctypes.c_uint32(index), _ptr(q),
+                                    ctypes.c_double(new_weight), ctypes.c_double(log_ratio)), "mcmcgpu_commit")
+
+    def rebuild(self):
+        self._check(self.lib.mcmcgpu_rebuild(self.h), "mcmcgpu_rebuild")
+
+    def log_likelihood(self):
+        out = np.empty(self.chains, dtype=np.float64)
+        self._check(self.lib.mcmcgpu_get_log_likelihood(self.h, _ptr(out)), "mcmcgpu_get_log_likelihood")
+        return out
+
+    def full_log_likelihood(self):
+        out = np.empty(self.chains, dtype=np.float64)
+        self._check(self.lib.mcmcgpu_full_log_likelihood(self.h, _ptr(out)), "mcmcgpu_full_log_likelihood")
+        return out
+
+    def dims(self):
+        t, f, c = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+        self._check(self.lib.mcmcgpu_get_dims(self.h, ctypes.byref(t), ctypes.byref(f), ctypes.byref(c)),
+                    "mcmcgpu_get_dims")
+        return t.value, f.value, c.value
+
+    def get_state(self, chain):
+        T, F, _ = self.dims()
+        st = {
+            "rel": np.empty((T, 3)),
+            "cum": np.empty((T + 1, 3)),
+            "feat_parent": np.empty(F, dtype=np.uint32),
+            "feat_est": np.empty((F, 2)),
+            "feat_world": np.empty((F, 2)),
+            "state_w": np.empty(T),
+            "feat_w": np.empty(F),
+        }
+        self._check(
+            self.lib.mcmcgpu_get_state(self.h, ctypes.c_uint32(chain), _ptr(st["rel"]), _ptr(st["cum"]),
+                                       _ptr(st["feat_parent"]), _ptr(st["feat_est"]), _ptr(st["feat_world"]),
+                                       _ptr(st["state_w"]), _ptr(st["feat_w"])), "mcmcgpu_get_state")
+        return st
+
+    def counters(self):
+        u = np.empty(self.chains, dtype=np.uint64)
+        a = np.empty(self.chains, dtype=np.uint64)
+        n = np.empty(self.chains, dtype=np.uint64)
+        self._check(self.lib.mcmcgpu_get_counters(self.h, _ptr(u), _ptr(a), _ptr(n)), "mcmcgpu_get_counters")
+        return u, a, n
+
+    def trace(self, chain):
+        out = np.zeros(max(self.trace_capacity, 1), dtype=STEP_RECORD)
+        n = ctypes.c_uint32()
+        self._check(
+            self.lib.mcmcgpu_get_trace(self.h, ctypes.c_uint32(chain), _ptr(out), ctypes.c_uint32(self.trace_capacity),
+                                       ctypes.byref(n)), "mcmcgpu_get_trace")
+        return out[:n.value]
+
+    def write_summaries(self, dev_ptr):
+        self._check(self.lib.mcmcgpu_write_summaries(self.h, ctypes.c_void_p(dev_ptr)), "mcmcgpu_write_summaries")
+
+    def export_state(self, chain, dev_ptr):
+        self._check(self.lib.mcmcgpu_export_state(self.h, ctypes.c_uint32(chain), ctypes.c_void_p(dev_ptr)),
+                    "mcmcgpu_export_state")
+
+    def import_state(self, chain, dev_ptr, log_likelihood):
+        self._check(
+            self.lib.mcmcgpu_import_state(self.h, ctypes.c_uint32(chain), ctypes.c_void_p(dev_ptr),
+                                          ctypes.c_double(log_likelihood)), "mcmcgpu_import_state")
+
+    def sync(self):
+        self._check(self.lib.mcmcgpu_sync(self.h), "mcmcgpu_sync")
+
+    def kernel_time(self):
+        ms, n = ctypes.c_double(), ctypes.c_uint32()
+        self._check(self.lib.mcmcgpu_kernel_time(self.h, ctypes.byref(ms), ctypes.byref(n)), "mcmcgpu_kernel_time")
+        return ms.value, n.value

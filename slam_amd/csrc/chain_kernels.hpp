@@ -1,0 +1,976 @@
+// Device kernels of the MCMC-SLAM path for gfx950 (MI355X).
+//
+// Execution model: ONE WORKGROUP PER CHAIN.  Chains never exchange data, so a
+// chain's whole Metropolis-Hastings loop -- edge selection, proposal, the
+// observation log-likelihood ratio, the accept test and the commit -- runs
+// inside one persistent workgroup for as many steps as the launch asks for.
+// Lane 0 of the workgroup is the "driver": it executes the short serial parts
+// of the reference algorithm (src/slam/mcmc_slam.hpp:339-418 and the graph
+// growth :227-336) and posts requests; all lanes then serve the data-parallel
+// parts together:
+//   * eval_state_edge / eval_feature_edge -- the fused observation
+//     log-likelihood-ratio reduction (mcmc_slam.hpp:432-505), HBM/L2 bound;
+//   * commit_state_edge -- the rigid re-positioning of the cumulative poses
+//     behind an accepted state edge.
+//
+// Cumulative poses (what the reference keeps in bitree<pose>) are stored in two
+// levels, struct-of-arrays: P[k] = block_offset[k >> sh] o local[k], local[]
+// being the prefix composition inside a block of 2^sh poses.  Any P[k] is O(1)
+// to read, and an accepted proposal at edge t touches at most 2^sh local poses
+// plus T/2^sh block offsets instead of every pose after t.  A range reading
+// only needs the TRANSLATION of P[s]: |P[s]^-1 w| = |w - t_s| for a world point
+// w, so the hot loop reads 16 B of pose per reading and no angle.
+#ifndef SLAM_AMD_CHAIN_KERNELS_HPP
+#define SLAM_AMD_CHAIN_KERNELS_HPP
+
+#include "../../include/mcmcgpu.h"
+#include "device_math.hpp"
+#include "scan.hpp"
+
+namespace mg {
+
+struct alignas(32) BlockXf {
+  double x, y, c, s;  // translation and cos/sin of the block's world pose
+};
+
+// Everything a kernel needs, passed by value.
+struct Dev {
+  // ---- problem (read-only), shared by all chains -------------------------
+  uint32_t T, F, N;           // uploaded sizes
+  uint32_t Tcap, Fcap, Ncap;  // capacities (array strides)
+  const double* cmu;          // [3][Tcap] control means
+  const double* csd;          // [3][Tcap] control std deviations
+  const uint32_t* foff;       // [Fcap+1] readings of landmark f: [foff[f], foff[f+1]), time-sorted
+  const uint32_t* ot;         // [Ncap] timestep of a reading (landmark-major order)
+  const double* omu;          // [Ncap] measured range
+  const double* osd;          // [Ncap] its std deviation
+  const uint32_t* ofeat;      // [Ncap] landmark of a reading
+  const uint32_t* toff;       // [Tcap+2] arrivals at timestep t: tobs[toff[t] .. toff[t+1])
+  const uint32_t* tobs;       // [Ncap] arrival order -> landmark-major position
+  const uint32_t* ffirst;     // [Fcap] timestep of a landmark's first reading
+  const double* init_u;       // [n_init_u] initialiser draws per landmark, or null
+  uint32_t n_init_u;
+  // ---- chains --------------------------------------------------------------
+  uint32_t C, sh, NBcap;
+  double *relx, *rely, *relth;  // [C][Tcap]   relative pose of state edge t
+  double *locx, *locy, *locth;  // [C][Tcap+1] block-local cumulative pose k
+  BlockXf* boff;                // [C][NBcap]  block world offset
+  double* bth;                  // [C][NBcap]  its angle
+  double *sw, *fw;              // [C][Tcap], [C][Fcap] weight trees
+  double *fex, *fey;            // [C][Fcap]   landmark estimate relative to its parent pose
+  uint32_t* fpar;               // [C][Fcap]   parent reading, as position inside the landmark's list
+  uint32_t* fcnt;               // [C][Fcap]   readings of the landmark seen so far
+  uint32_t* fpt;                // [C][Fcap]   parent timestep
+  uint32_t* flast;              // [C][Fcap]   timestep of the latest reading seen
+  uint32_t* nf;                 // [C]         landmarks known
+  double* ll;                   // [C]         chain log likelihood
+  uint32_t* mt;                 // [C][624]
+  int32_t* mti;                 // [C]
+  int32_t* nflag;               // [C]
+  double* nsaved;               // [C]
+  unsigned long long *n_updates, *n_accepts, *n_units;  // [C]
+  uint32_t* errflag;            // [C]
+  mcmcgpu_step_record* trace;   // [C][trace_cap] or null
+  uint32_t trace_cap;
+  uint32_t* trace_n;  // [C]
+  int32_t uniform_first;
+};
+
+constexpr int kMaxSeg = 256;    // landmark segments evaluated per pass
+constexpr int kActCap = 1024;   // landmarks examined per round (blockDim.x divides it)
+constexpr int kMaxWaves = 16;
+constexpr uint32_t kMaxRetry = 1u << 16;
+
+enum Op : int { OP_END = 0, OP_EVAL_STATE = 1, OP_EVAL_FEATURE = 2 };
+enum Pending : int { PEND_NONE = 0, PEND_UPDATE = 1, PEND_REPARENT = 2 };
+enum Stage : int { ST_EDGE = 0, ST_ARRIVALS = 1, ST_STEPS = 2, ST_NEXT = 3, ST_END_STEPS = 4, ST_DONE = 5 };
+
+struct Shared {
+  RngState rng;
+  // driver state (lane 0 only)
+  int stage;
+  uint32_t tn, upto, arr, arr_end, steps_left, steps_per_ts, end_left;
+  uint32_t Tcur, nf;
+  double ll;
+  int pending, use_weight;
+  double new_pll, old_pll;
+  uint32_t rp_obs;
+  unsigned long long n_upd, n_acc, n_units;
+  uint32_t failed;
+  // request posted by the driver
+  int op;
+  uint32_t idx;
+  double q[3];
+  int accept;
+  // evaluation scratch
+  uint32_t nact;
+  uint32_t act[kActCap];
+  uint32_t segpre[kMaxSeg + 1];
+  uint32_t seglo[kMaxSeg];
+  double segw[kMaxSeg][4];  // old landmark (x,y), new landmark (x,y), world frame
+  uint32_t wcount[kMaxWaves];
+  double red[kMaxWaves];
+  Pose stage_pose[kMaxWaves];
+};
+
+// ---------------------------------------------------------------------------
+// cumulative pose access
+
+MG_DEV Pose world_pose(const Dev& d, uint32_t c, uint32_t k) {
+  const size_t li = size_t(c) * (d.Tcap + 1) + k;
+  const size_t bi = size_t(c) * d.NBcap + (k >> d.sh);
+  const BlockXf xf = d.boff[bi];
+  const double lx = d.locx[li], ly = d.locy[li];
+  return Pose{xf.x + (xf.c * lx - xf.s * ly), xf.y + (xf.s * lx + xf.c * ly), d.bth[bi] + d.locth[li]};
+}
+
+// Appends pose Tcur+1 = P[Tcur] o rel (lane 0, graph growth).
+MG_DEV void append_pose(const Dev& d, uint32_t c, uint32_t Tcur, const Pose& rel) {
+  const uint32_t k = Tcur + 1;
+  const size_t base = size_t(c) * (d.Tcap + 1);
+  const Pose lprev{d.locx[base + Tcur], d.locy[base + Tcur], d.locth[base + Tcur]};
+  const Pose lnew = compose(lprev, rel);
+  if ((k & ((1u << d.sh) - 1)) == 0) {
+    const size_t bprev = size_t(c) * d.NBcap + (Tcur >> d.sh);
+    const BlockXf xf = d.boff[bprev];
+    const Pose w{xf.x + (xf.c * lnew.x - xf.s * lnew.y), xf.y + (xf.s * lnew.x + xf.c * lnew.y),
+                 d.bth[bprev] + lnew.th};
+    double s, co;
+    sincos(w.th, &s, &co);
+    d.boff[bprev + 1] = BlockXf{w.x, w.y, co, s};
+    d.bth[bprev + 1] = w.th;
+    d.locx[base + k] = 0.0;
+    d.locy[base + k] = 0.0;
+    d.locth[base + k] = 0.0;
+  } else {
+    d.locx[base + k] = lnew.x;
+    d.locy[base + k] = lnew.y;
+    d.locth[base + k] = lnew.th;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// workgroup helpers
+
+MG_DEV uint32_t block_scan_u32(uint32_t v, Shared& S, uint32_t& total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+#pragma unroll
+  for (int dd = 1; dd < 64; dd <<= 1) {
+    const uint32_t o = __shfl_up(v, dd);
+    if (lane >= dd) v += o;
+  }
+  if (lane == 63) S.wcount[wave] = v;
+  __syncthreads();
+  uint32_t before = 0, all = 0;
+  for (int w = 0; w < nwaves; ++w) {
+    if (w == wave) before = all;
+    all += S.wcount[w];
+  }
+  total = all;
+  __syncthreads();
+  return v + before;  // inclusive
+}
+
+// Sum over the workgroup in a fixed order; the result is valid in lane 0.
+MG_DEV double block_sum(double v, Shared& S) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+#pragma unroll
+  for (int dd = 32; dd > 0; dd >>= 1) v += __shfl_down(v, dd);
+  if (lane == 0) S.red[wave] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < nwaves; ++w) r += S.red[w];
+  __syncthreads();
+  return r;
+}
+
+// ---------------------------------------------------------------------------
+// The fused observation kernel body: all lanes stream the readings of the
+// prepared segments, gather the pose translation of each reading's timestep
+// and accumulate
+//   FULL == false:  ll(|w_new - t_s|) - ll(|w_old - t_s|)     (mcmc_slam.hpp:487-502)
+//   FULL == true :  ll(|w_old - t_s|) with its constants       (slam_likelihood.hpp:48-54)
+template <bool FULL>
+MG_DEV double eval_segments(const Dev& d, uint32_t c, const Shared& S, uint32_t nseg) {
+  const uint32_t total = S.segpre[nseg];
+  const size_t lbase = size_t(c) * (d.Tcap + 1);
+  const double* __restrict__ locx = d.locx + lbase;
+  const double* __restrict__ locy = d.locy + lbase;
+  const BlockXf* __restrict__ boff = d.boff + size_t(c) * d.NBcap;
+  const uint32_t* __restrict__ ot = d.ot;
+  const double* __restrict__ omu = d.omu;
+  const double* __restrict__ osd = d.osd;
+  double acc = 0.0;
+  uint32_t cur = 0;
+  for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) {
+    while (i >= S.segpre[cur + 1]) ++cur;
+    const uint32_t o = S.seglo[cur] + (i - S.segpre[cur]);
+    const uint32_t s = ot[o];
+    const double mu = omu[o];
+    const double sd = osd[o];
+    const BlockXf xf = boff[s >> d.sh];
+    const double lx = locx[s], ly = locy[s];
+    const double px = xf.x + (xf.c * lx - xf.s * ly);
+    const double py = xf.y + (xf.s * lx + xf.c * ly);
+    const double ox = S.segw[cur][0] - px, oy = S.segw[cur][1] - py;
+    const double zo = (sqrt(ox * ox + oy * oy) - mu) / sd;
+    if (FULL) {
+      acc += -0.5 * (zo * zo) - 0.5 * log(2 * kPi) - log(sd);
+    } else {
+      const double nx = S.segw[cur][2] - px, ny = S.segw[cur][3] - py;
+      const double zn = (sqrt(nx * nx + ny * ny) - mu) / sd;
+      acc += (-0.5 * (zn * zn)) - (-0.5 * (zo * zo));
+    }
+  }
+  return acc;
+}
+
+// Landmark edge (mcmc_slam.hpp:468-474): every reading of landmark f seen so
+// far, old estimate against `e_new`, both relative to the parent pose.
+MG_DEV double eval_feature_edge(const Dev& d, uint32_t c, Shared& S, uint32_t f, const Vec2& e_new,
+                                unsigned long long& units) {
+  const size_t fi = size_t(c) * d.Fcap + f;
+  if (threadIdx.x == 0) {
+    const Pose Pp = world_pose(d, c, d.fpt[fi]);
+    const Vec2 wo = act(Pp, Vec2{d.fex[fi], d.fey[fi]});
+    const Vec2 wn = act(Pp, e_new);
+    S.seglo[0] = d.foff[f];
+    S.segpre[0] = 0;
+    S.segpre[1] = d.fcnt[fi];
+    S.segw[0][0] = wo.x;
+    S.segw[0][1] = wo.y;
+    S.segw[0][2] = wn.x;
+    S.segw[0][3] = wn.y;
+  }
+  __syncthreads();
+  units += S.segpre[1];
+  const double acc = eval_segments<false>(d, c, S, 1);
+  return block_sum(acc, S);
+}
+
+// State edge (mcmc_slam.hpp:432-466), observation part only.  Replacing the
+// relative pose of edge t by q moves every pose after t rigidly.  For a
+// landmark whose parent pose is after t the landmark moves with it and the
+// readings taken up to t are affected; otherwise the landmark stays and the
+// readings after t are affected.  Either way the affected readings compare
+// |w_new - t_s| with |w_old - t_s| on the UNCHANGED pose table.
+MG_DEV double eval_state_edge(const Dev& d, uint32_t c, Shared& S, uint32_t t, const Pose& q, uint32_t nf,
+                              unsigned long long& units) {
+  const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+  const uint32_t segcap = nthr < uint32_t(kMaxSeg) ? nthr : uint32_t(kMaxSeg);
+  const Pose Pt = world_pose(d, c, t), Pt1 = world_pose(d, c, t + 1);
+  const Pose qinv = inverse(q);
+  const size_t fbase = size_t(c) * d.Fcap;
+  double acc = 0.0;
+  const uint32_t per = uint32_t(kActCap) / nthr;  // landmarks examined per lane and round (1..16)
+  for (uint32_t f0 = 0; f0 < nf; f0 += uint32_t(kActCap)) {
+    // A: which landmarks have affected readings?  first <= t < last
+    uint32_t flags = 0;
+    for (uint32_t k = 0; k < per; ++k) {
+      const uint32_t f = f0 + tid * per + k;
+      if (f < nf) {
+        const uint32_t first = d.ffirst[f], last = d.flast[fbase + f];
+        if (first <= t && t < last) flags |= 1u << k;
+      }
+    }
+    const uint32_t cnt = __popc(flags);
+    uint32_t nact;
+    uint32_t at = block_scan_u32(cnt, S, nact) - cnt;
+    for (uint32_t k = 0; k < per; ++k)
+      if ((flags >> k) & 1u) S.act[at++] = f0 + tid * per + k;
+    __syncthreads();
+    for (uint32_t a0 = 0; a0 < nact; a0 += segcap) {
+      const uint32_t nseg = (nact - a0) < segcap ? (nact - a0) : segcap;
+      // B: one lane per active landmark: split its reading list at t, move it
+      uint32_t len = 0;
+      if (tid < nseg) {
+        const uint32_t f = S.act[a0 + tid];
+        const uint32_t lo = d.foff[f], hi = lo + d.fcnt[fbase + f];
+        uint32_t a = lo, b = hi;  // upper_bound(ot[lo..hi), t)
+        while (a < b) {
+          const uint32_t m = (a + b) >> 1;
+          if (d.ot[m] <= t)
+            a = m + 1;
+          else
+            b = m;
+        }
+        const uint32_t pt = d.fpt[fbase + f];
+        const Vec2 w = act(world_pose(d, c, pt), Vec2{d.fex[fbase + f], d.fey[fbase + f]});
+        Vec2 wn;
+        uint32_t slo, shi;
+        if (t < pt) {  // landmark hangs off a pose that moves
+          wn = act(Pt, act(q, act_inverse(Pt1, w)));
+          slo = lo;
+          shi = a;
+        } else {  // poses after t move, seen from them the landmark moves by the inverse
+          wn = act(Pt1, act(qinv, act_inverse(Pt, w)));
+          slo = a;
+          shi = hi;
+        }
+        S.seglo[tid] = slo;
+        S.segw[tid][0] = w.x;
+        S.segw[tid][1] = w.y;
+        S.segw[tid][2] = wn.x;
+        S.segw[tid][3] = wn.y;
+        len = shi - slo;
+      }
+      uint32_t total;
+      const uint32_t incl = block_scan_u32(len, S, total);
+      if (tid < nseg) S.segpre[tid + 1] = incl;
+      if (tid == 0) S.segpre[0] = 0;
+      __syncthreads();
+      units += total;
+      // C: stream the affected readings
+      acc += eval_segments<false>(d, c, S, nseg);
+      __syncthreads();
+    }
+  }
+  return block_sum(acc, S);
+}
+
+// Accepted state edge t <- q: P'[k] = P[k] (k <= t), D o P[k] (k > t) with
+// D = P[t] o q o P[t+1]^-1, applied as a rotation about the old P[t+1] so no
+// large coordinates cancel.  Inside the block of pose t+1 the block-local
+// poses are updated, after it only the block offsets.
+MG_DEV void commit_state_edge(const Dev& d, uint32_t c, uint32_t t, const Pose& q, uint32_t Tcur) {
+  const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+  const uint32_t bsz = 1u << d.sh;
+  const uint32_t k1 = t + 1, b1 = k1 >> d.sh, k0 = b1 << d.sh;
+  const bool at_block_start = (k1 == k0);
+  const size_t lbase = size_t(c) * (d.Tcap + 1);
+  const size_t bbase = size_t(c) * d.NBcap;
+  const Pose Pt = world_pose(d, c, t), Pt1 = world_pose(d, c, k1);
+  const Pose A = compose(Pt, q);
+  const double Dth = q.th - d.relth[size_t(c) * d.Tcap + t];
+  double sD, cD;
+  sincos(Dth, &sD, &cD);
+  Pose Lt1 = pose_identity(), Al = pose_identity();
+  if (!at_block_start) {
+    const Pose Lt{d.locx[lbase + t], d.locy[lbase + t], d.locth[lbase + t]};
+    Lt1 = Pose{d.locx[lbase + k1], d.locy[lbase + k1], d.locth[lbase + k1]};
+    Al = compose(Lt, q);
+  }
+  __syncthreads();  // every lane holds the old values before anything is overwritten
+  if (!at_block_start) {
+    const uint32_t kend = (k0 + bsz - 1) < Tcur ? (k0 + bsz - 1) : Tcur;
+    for (uint32_t k = k1 + tid; k <= kend; k += nthr) {
+      const double lx = d.locx[lbase + k] - Lt1.x, ly = d.locy[lbase + k] - Lt1.y;
+      d.locx[lbase + k] = Al.x + (cD * lx - sD * ly);
+      d.locy[lbase + k] = Al.y + (sD * lx + cD * ly);
+      d.locth[lbase + k] += Dth;
+    }
+  }
+  const uint32_t bfirst = at_block_start ? b1 : b1 + 1, blast = Tcur >> d.sh;
+  for (uint32_t b = bfirst + tid; b <= blast; b += nthr) {
+    const BlockXf xf = d.boff[bbase + b];
+    const double dx = xf.x - Pt1.x, dy = xf.y - Pt1.y;
+    const double nth = d.bth[bbase + b] + Dth;
+    double s, co;
+    sincos(nth, &s, &co);
+    d.boff[bbase + b] = BlockXf{A.x + (cD * dx - sD * dy), A.y + (sD * dx + cD * dy), co, s};
+    d.bth[bbase + b] = nth;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// The driver: lane 0's resumable restatement of mcmc_slam::timestep / update.
+
+MG_DEV void load_control(const Dev& d, uint32_t t, double mu[3], double sd[3]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    mu[i] = d.cmu[size_t(i) * d.Tcap + t];
+    sd[i] = d.csd[size_t(i) * d.Tcap + t];
+  }
+}
+
+MG_DEV void write_trace(const Dev& d, uint32_t c, Shared& S, int kind, uint32_t idx, const double q[3], double llr,
+                        int accepted) {
+  if (!d.trace) return;
+  const uint32_t n = d.trace_n[c];
+  if (n < d.trace_cap) {
+    mcmcgpu_step_record& r = d.trace[size_t(c) * d.trace_cap + n];
+    r.kind = kind;
+    r.accepted = accepted;
+    r.index = idx;
+    r.proposed[0] = q[0];
+    r.proposed[1] = q[1];
+    r.proposed[2] = q[2];
+    r.log_ratio = llr;
+    r.log_likelihood = S.ll;
+  }
+  d.trace_n[c] = n + 1;
+}
+
+// mcmc_slam::add_state_edge (mcmc_slam.hpp:227-246) for edge Tcur
+MG_DEV void driver_add_state_edge(const Dev& d, uint32_t c, Shared& S) {
+  const uint32_t t = S.Tcur;
+  double mu[3], sd[3];
+  load_control(d, t, mu, sd);
+  const Pose est = control_inv_observe(mu);
+  const size_t ri = size_t(c) * d.Tcap + t;
+  d.relx[ri] = est.x;
+  d.rely[ri] = est.y;
+  d.relth[ri] = est.th;
+  append_pose(d, c, t, est);
+  const double lp = control_log_pdf(mu, sd, est);
+  wt::push_back(d.sw + size_t(c) * d.Tcap, t, edge_weight_from_log_pdf(lp, 3.0, nullptr));
+  S.ll += lp;
+  S.Tcur = t + 1;
+}
+
+// Selection and proposal of one update (mcmc_slam.hpp:339-368, :375-382).
+// Returns false when nothing can be updated (both weight totals zero, :345).
+MG_DEV bool driver_begin_update(const Dev& d, uint32_t c, Shared& S) {
+  const double* sw = d.sw + size_t(c) * d.Tcap;
+  const double* fw = d.fw + size_t(c) * d.Fcap;
+  const double Ws = wt::total(sw, S.Tcur), Wf = wt::total(fw, S.nf);
+  if (Ws == 0 && Wf == 0) return false;
+  uint32_t retry = 0;
+  if ((Ws + Wf) * rng_uniform(S.rng) < Ws) {
+    uint32_t t;
+    do {
+      t = wt::search(sw, S.Tcur, Ws * rng_uniform(S.rng));
+    } while (t >= S.Tcur && ++retry < kMaxRetry);
+    if (t >= S.Tcur) {
+      S.failed = 1;
+      return false;
+    }
+    double mu[3], sd[3], v[3];
+    load_control(d, t, mu, sd);
+    for (int i = 0; i < 3; ++i) v[i] = rng_normal(S.rng);
+    for (int i = 0; i < 3; ++i) v[i] = v[i] * sd[i] + mu[i];
+    const Pose q = control_inv_observe(v);
+    const size_t ri = size_t(c) * d.Tcap + t;
+    const Pose cur{d.relx[ri], d.rely[ri], d.relth[ri]};
+    S.new_pll = control_log_pdf(mu, sd, q);
+    S.old_pll = control_log_pdf(mu, sd, cur);
+    S.op = OP_EVAL_STATE;
+    S.idx = t;
+    S.q[0] = q.x;
+    S.q[1] = q.y;
+    S.q[2] = q.th;
+  } else {
+    uint32_t f;
+    do {
+      f = wt::search(fw, S.nf, Wf * rng_uniform(S.rng));
+    } while (f >= S.nf && ++retry < kMaxRetry);
+    if (f >= S.nf) {
+      S.failed = 1;
+      return false;
+    }
+    const size_t fi = size_t(c) * d.Fcap + f;
+    const uint32_t po = d.foff[f] + d.fpar[fi];
+    const double mu = d.omu[po], sd = d.osd[po];
+    double r, u;
+    if (d.uniform_first) {
+      u = rng_uniform(S.rng);
+      r = rng_normal(S.rng) * sd + mu;
+    } else {
+      r = rng_normal(S.rng) * sd + mu;
+      u = rng_uniform(S.rng);
+    }
+    const Vec2 q = polar(r, u * 2 * kPi);
+    S.new_pll = range_proposal_log_pdf(mu, sd, q);
+    S.old_pll = range_proposal_log_pdf(mu, sd, Vec2{d.fex[fi], d.fey[fi]});
+    S.op = OP_EVAL_FEATURE;
+    S.idx = f;
+    S.q[0] = q.x;
+    S.q[1] = q.y;
+    S.q[2] = 0.0;
+  }
+  S.pending = PEND_UPDATE;
+  S.use_weight = 1;
+  return true;
+}
+
+// The rest of mcmc_slam::update(EdgeType&&, bool) (:385-418) once the
+// observation part of the log ratio is known.  Returns the accept decision;
+// pose tables of an accepted state edge are moved afterwards by all lanes.
+MG_DEV bool driver_finish_update(const Dev& d, uint32_t c, Shared& S, double obs_ratio) {
+  const bool is_state = (S.op == OP_EVAL_STATE);
+  const double dim = is_state ? 3.0 : 2.0;
+  const double proposal_log_ratio = S.new_pll - S.old_pll;
+  // state edge: the control term of :436-438 is the same pair of numbers
+  const double log_ratio = is_state ? (S.new_pll - S.old_pll) + obs_ratio : obs_ratio;
+  double new_log_weight;
+  const double new_weight = edge_weight_from_log_pdf(S.new_pll, dim, &new_log_weight);
+  double normaliser = 1.0;
+  double accept_log_ratio = log_ratio - proposal_log_ratio;
+  double* sw = d.sw + size_t(c) * d.Tcap;
+  double* fw = d.fw + size_t(c) * d.Fcap;
+  if (S.use_weight) {
+    double old_log_weight;
+    const double old_weight = edge_weight_from_log_pdf(S.old_pll, dim, &old_log_weight);
+    const double weight_sum = wt::total(sw, S.Tcur) + wt::total(fw, S.nf);
+    normaliser += (new_weight - old_weight) / weight_sum;
+    accept_log_ratio += new_log_weight - old_log_weight;
+  }
+  const bool accept = normaliser * rng_uniform(S.rng) < exp(accept_log_ratio);
+  if (accept) {
+    if (is_state) {
+      wt::set(sw, S.Tcur, S.idx, new_weight);
+      // the relative pose itself is stored by commit_state_edge's caller after
+      // the pose tables have been moved (they need the old angle)
+    } else {
+      const size_t fi = size_t(c) * d.Fcap + S.idx;
+      d.fex[fi] = S.q[0];
+      d.fey[fi] = S.q[1];
+      wt::set(fw, S.nf, S.idx, new_weight);
+    }
+    S.ll += log_ratio;
+  }
+  write_trace(d, c, S, is_state ? 0 : 1, S.idx, S.q, log_ratio, accept ? 1 : 0);
+  return accept;
+}
+
+// One arrival during growth (mcmc_slam.hpp:283-331).  Returns true when a
+// re-parenting update was posted and needs the workgroup.
+MG_DEV bool driver_arrival(const Dev& d, uint32_t c, Shared& S, uint32_t o) {
+  const uint32_t f = d.ofeat[o];
+  const size_t fi = size_t(c) * d.Fcap + f;
+  const uint32_t t = S.tn;
+  const double mu = d.omu[o], sd = d.osd[o];
+  if (o == d.foff[f]) {  // first reading of this landmark: add_feature_edge, :248-270
+    const double u = (d.init_u && f < d.n_init_u) ? d.init_u[f] : rng_uniform(S.rng);
+    const Vec2 est = polar(mu, u * 2 * kPi);
+    d.fex[fi] = est.x;
+    d.fey[fi] = est.y;
+    d.fpar[fi] = 0;
+    d.fcnt[fi] = 1;
+    d.fpt[fi] = t;
+    d.flast[fi] = t;
+    wt::push_back(d.fw + size_t(c) * d.Fcap, f,
+                  edge_weight_from_log_pdf(range_proposal_log_pdf(mu, sd, est), 2.0, nullptr));
+    S.ll += range_log_pdf(mu, sd, vec_norm(est));
+    S.nf = f + 1;
+    return false;
+  }
+  const uint32_t rel = o - d.foff[f];
+  d.fcnt[fi] = rel + 1;
+  d.flast[fi] = t;
+  const uint32_t pt = d.fpt[fi];
+  const Vec2 w = act(world_pose(d, c, pt), Vec2{d.fex[fi], d.fey[fi]});
+  const Vec2 est = act_inverse(world_pose(d, c, t), w);
+  S.ll += range_log_pdf(mu, sd, vec_norm(est));
+  const double par_mu = d.omu[d.foff[f] + d.fpar[fi]];
+  if (fabs(mu) < fabs(par_mu)) {  // more_accurate_than, range_bearing_model.hpp:141-143
+    d.fpar[fi] = rel;
+    d.fpt[fi] = t;
+    d.fex[fi] = est.x;
+    d.fey[fi] = est.y;
+    // update(feature_edge, false), :320
+    double r, u;
+    if (d.uniform_first) {
+      u = rng_uniform(S.rng);
+      r = rng_normal(S.rng) * sd + mu;
+    } else {
+      r = rng_normal(S.rng) * sd + mu;
+      u = rng_uniform(S.rng);
+    }
+    const Vec2 q = polar(r, u * 2 * kPi);
+    S.new_pll = range_proposal_log_pdf(mu, sd, q);
+    S.old_pll = range_proposal_log_pdf(mu, sd, est);
+    S.op = OP_EVAL_FEATURE;
+    S.idx = f;
+    S.q[0] = q.x;
+    S.q[1] = q.y;
+    S.q[2] = 0.0;
+    S.pending = PEND_REPARENT;
+    S.use_weight = 0;
+    S.rp_obs = o;
+    return true;
+  }
+  return false;
+}
+
+// Runs lane 0's program until it needs the workgroup (a request is posted in
+// S.op) or is finished (S.op = OP_END).
+MG_DEV void driver_advance(const Dev& d, uint32_t c, Shared& S) {
+  for (;;) {
+    if (S.failed) {
+      S.op = OP_END;
+      return;
+    }
+    switch (S.stage) {
+      case ST_EDGE:
+        if (S.tn > S.upto) {
+          S.stage = ST_END_STEPS;
+          break;
+        }
+        if (S.tn > 0) driver_add_state_edge(d, c, S);
+        S.arr = d.toff[S.tn];
+        S.arr_end = d.toff[S.tn + 1];
+        S.stage = ST_ARRIVALS;
+        break;
+      case ST_ARRIVALS:
+        while (S.arr < S.arr_end) {
+          const uint32_t o = d.tobs[S.arr++];
+          if (driver_arrival(d, c, S, o)) return;
+        }
+        S.steps_left = S.steps_per_ts;
+        S.stage = ST_STEPS;
+        break;
+      case ST_STEPS:
+        while (S.steps_left > 0) {
+          --S.steps_left;
+          ++S.n_upd;
+          if (driver_begin_update(d, c, S)) return;
+        }
+        S.stage = ST_NEXT;
+        break;
+      case ST_NEXT:
+        ++S.tn;
+        S.stage = ST_EDGE;
+        break;
+      case ST_END_STEPS:
+        while (S.end_left > 0) {
+          --S.end_left;
+          ++S.n_upd;
+          if (driver_begin_update(d, c, S)) return;
+        }
+        S.stage = ST_DONE;
+        break;
+      default:
+        S.op = OP_END;
+        return;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// kernels
+
+// Loads / stores the per-chain state that lives in LDS while a kernel runs.
+MG_DEV void chain_state_load(const Dev& d, uint32_t c, Shared& S) {
+  for (uint32_t i = threadIdx.x; i < 624; i += blockDim.x) S.rng.mt[i] = d.mt[size_t(c) * 624 + i];
+  if (threadIdx.x == 0) {
+    S.rng.idx = d.mti[c];
+    S.rng.has_saved = d.nflag[c];
+    S.rng.saved = d.nsaved[c];
+    S.nf = d.nf[c];
+    S.ll = d.ll[c];
+    S.n_upd = 0;
+    S.n_acc = 0;
+    S.n_units = 0;
+    S.failed = 0;
+    S.pending = PEND_NONE;
+  }
+}
+MG_DEV void chain_state_store(const Dev& d, uint32_t c, Shared& S) {
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < 624; i += blockDim.x) d.mt[size_t(c) * 624 + i] = S.rng.mt[i];
+  if (threadIdx.x == 0) {
+    d.mti[c] = S.rng.idx;
+    d.nflag[c] = S.rng.has_saved;
+    d.nsaved[c] = S.rng.saved;
+    d.nf[c] = S.nf;
+    d.ll[c] = S.ll;
+    d.n_updates[c] += S.n_upd;
+    d.n_accepts[c] += S.n_acc;
+    d.n_units[c] += S.n_units;
+    if (S.failed) d.errflag[c] = 1;
+  }
+}
+
+// grid = chains, block = threads_per_chain.  first_tn = the next timestep the
+// chains have not processed yet; Tcur0 = state edges grown so far.
+__global__ void advance_kernel(Dev d, uint32_t first_tn, uint32_t Tcur0, uint32_t upto, uint32_t steps_per_ts,
+                               uint32_t end_steps, uint32_t grow) {
+  __shared__ Shared S;
+  const uint32_t c = blockIdx.x;
+  chain_state_load(d, c, S);
+  if (threadIdx.x == 0) {
+    S.Tcur = Tcur0;
+    S.tn = first_tn;
+    S.upto = upto;
+    S.steps_per_ts = steps_per_ts;
+    S.end_left = end_steps;
+    S.stage = grow ? ST_EDGE : ST_END_STEPS;
+  }
+  __syncthreads();
+  for (;;) {
+    if (threadIdx.x == 0) driver_advance(d, c, S);
+    __syncthreads();
+    const int op = S.op;
+    if (op == OP_END) break;
+    const uint32_t idx = S.idx;
+    const Pose q{S.q[0], S.q[1], S.q[2]};
+    const uint32_t Tcur = S.Tcur, nf = S.nf;
+    unsigned long long units = 0;
+    double r;
+    if (op == OP_EVAL_STATE)
+      r = eval_state_edge(d, c, S, idx, q, nf, units);
+    else
+      r = eval_feature_edge(d, c, S, idx, Vec2{q.x, q.y}, units);
+    if (threadIdx.x == 0) {
+      S.n_units += units;
+      const bool accept = driver_finish_update(d, c, S, r);
+      S.accept = accept ? 1 : 0;
+      if (S.pending == PEND_UPDATE) {
+        if (accept) ++S.n_acc;
+      } else if (!accept) {  // rejected re-parenting update: reset the edge weight, :321-322
+        const uint32_t o = S.rp_obs;
+        const size_t fi = size_t(c) * d.Fcap + idx;
+        wt::set(d.fw + size_t(c) * d.Fcap, S.nf, idx,
+                edge_weight_from_log_pdf(
+                    range_proposal_log_pdf(d.omu[o], d.osd[o], Vec2{d.fex[fi], d.fey[fi]}), 2.0, nullptr));
+      }
+      S.pending = PEND_NONE;
+    }
+    __syncthreads();
+    if (op == OP_EVAL_STATE && S.accept) {
+      commit_state_edge(d, c, idx, q, Tcur);
+      if (threadIdx.x == 0) {
+        const size_t ri = size_t(c) * d.Tcap + idx;
+        d.relx[ri] = q.x;
+        d.rely[ri] = q.y;
+        d.relth[ri] = q.th;
+      }
+    }
+    __syncthreads();
+  }
+  chain_state_store(d, c, S);
+}
+
+// edge_log_likelihood_ratio for a caller-supplied proposal; grid = 1.
+__global__ void eval_kernel(Dev d, uint32_t c, int kind, uint32_t idx, double q0, double q1, double q2,
+                            uint32_t Tcur, double* out) {
+  __shared__ Shared S;
+  unsigned long long units = 0;
+  double r;
+  if (kind == MCMCGPU_STATE_EDGE) {
+    const Pose q{q0, q1, q2};
+    r = eval_state_edge(d, c, S, idx, q, d.nf[c], units);
+    if (threadIdx.x == 0) {
+      double mu[3], sd[3];
+      load_control(d, idx, mu, sd);
+      const size_t ri = size_t(c) * d.Tcap + idx;
+      const Pose cur{d.relx[ri], d.rely[ri], d.relth[ri]};
+      r = (control_log_pdf(mu, sd, q) - control_log_pdf(mu, sd, cur)) + r;
+    }
+  } else {
+    r = eval_feature_edge(d, c, S, idx, Vec2{q0, q1}, units);
+  }
+  (void)Tcur;
+  if (threadIdx.x == 0) *out = r;
+}
+
+// The accept branch applied from outside; grid = 1.
+__global__ void commit_kernel(Dev d, uint32_t c, int kind, uint32_t idx, double q0, double q1, double q2,
+                              double new_weight, double log_ratio, uint32_t Tcur) {
+  if (kind == MCMCGPU_STATE_EDGE) {
+    const Pose q{q0, q1, q2};
+    commit_state_edge(d, c, idx, q, Tcur);
+    if (threadIdx.x == 0) {
+      const size_t ri = size_t(c) * d.Tcap + idx;
+      d.relx[ri] = q.x;
+      d.rely[ri] = q.y;
+      d.relth[ri] = q.th;
+      wt::set(d.sw + size_t(c) * d.Tcap, Tcur, idx, new_weight);
+      d.ll[c] += log_ratio;
+    }
+  } else if (threadIdx.x == 0) {
+    const size_t fi = size_t(c) * d.Fcap + idx;
+    d.fex[fi] = q0;
+    d.fey[fi] = q1;
+    wt::set(d.fw + size_t(c) * d.Fcap, d.nf[c], idx, new_weight);
+    d.ll[c] += log_ratio;
+  }
+}
+
+// ---- cumulative pose rebuild: two-level SE(2) scan --------------------------
+// level 1: grid = (blocks of poses, chains), block = 2^sh lanes.  Lane j of
+// tile b composes rel[k0 .. k0+j]; the tile total goes to `tot`.
+__global__ void scan_local_kernel(Dev d, uint32_t Tcur, Pose* tot) {
+  __shared__ Pose stage[kMaxWaves];
+  const uint32_t c = blockIdx.y, b = blockIdx.x, j = threadIdx.x;
+  const uint32_t k0 = b << d.sh, k = k0 + j;
+  const size_t rbase = size_t(c) * d.Tcap, lbase = size_t(c) * (d.Tcap + 1);
+  Pose v = pose_identity();
+  if (k < Tcur) v = Pose{d.relx[rbase + k], d.rely[rbase + k], d.relth[rbase + k]};
+  Pose total;
+  const Pose inc = block_scan_inclusive(v, PoseOp{}, stage, total);
+  if (j == 0) {
+    d.locx[lbase + k0] = 0.0;
+    d.locy[lbase + k0] = 0.0;
+    d.locth[lbase + k0] = 0.0;
+  }
+  if (j + 1 < blockDim.x && k + 1 <= Tcur) {
+    d.locx[lbase + k + 1] = inc.x;
+    d.locy[lbase + k + 1] = inc.y;
+    d.locth[lbase + k + 1] = inc.th;
+  }
+  if (j == blockDim.x - 1) tot[size_t(c) * d.NBcap + b] = total;
+}
+
+// level 2: grid = chains.  Exclusive scan of the tile totals -> block offsets.
+__global__ void scan_offsets_kernel(Dev d, uint32_t nblocks, const Pose* tot) {
+  __shared__ Pose stage[kMaxWaves];
+  const uint32_t c = blockIdx.x;
+  const size_t bbase = size_t(c) * d.NBcap;
+  Pose carry = pose_identity();
+  if (threadIdx.x == 0) {
+    d.boff[bbase] = BlockXf{0.0, 0.0, 1.0, 0.0};
+    d.bth[bbase] = 0.0;
+  }
+  for (uint32_t b0 = 0; b0 + 1 < nblocks; b0 += blockDim.x) {
+    const uint32_t b = b0 + threadIdx.x;
+    Pose v = pose_identity();
+    if (b + 1 < nblocks) v = tot[bbase + b];
+    Pose total;
+    Pose inc = block_scan_inclusive(v, PoseOp{}, stage, total);
+    inc = compose(carry, inc);
+    if (b + 1 < nblocks) {
+      double s, co;
+      sincos(inc.th, &s, &co);
+      d.boff[bbase + b + 1] = BlockXf{inc.x, inc.y, co, s};
+      d.bth[bbase + b + 1] = inc.th;
+    }
+    carry = compose(carry, total);
+  }
+}
+
+// World poses of one chain, k = 0..Tcur, as [k][3].
+__global__ void materialize_kernel(Dev d, uint32_t c, uint32_t Tcur, double* out) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k <= Tcur) {
+    const Pose p = world_pose(d, c, k);
+    out[3 * size_t(k)] = p.x;
+    out[3 * size_t(k) + 1] = p.y;
+    out[3 * size_t(k) + 2] = p.th;
+  }
+}
+
+// World landmark positions and plain edge weights of one chain.
+__global__ void readout_kernel(Dev d, uint32_t c, uint32_t Tcur, double* feat_world, double* state_w,
+                               double* feat_w) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t nf = d.nf[c];
+  if (i < nf) {
+    const size_t fi = size_t(c) * d.Fcap + i;
+    const Vec2 w = act(world_pose(d, c, d.fpt[fi]), Vec2{d.fex[fi], d.fey[fi]});
+    feat_world[2 * size_t(i)] = w.x;
+    feat_world[2 * size_t(i) + 1] = w.y;
+    feat_w[i] = wt::get(d.fw + size_t(c) * d.Fcap, i);
+  }
+  if (i < Tcur) state_w[i] = wt::get(d.sw + size_t(c) * d.Tcap, i);
+}
+
+// slam_log_likelihood (src/slam/slam_likelihood.hpp:26-58); grid = chains.
+__global__ void full_ll_kernel(Dev d, uint32_t Tcur, double* out) {
+  __shared__ Shared S;
+  const uint32_t c = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  const uint32_t segcap = nthr < uint32_t(kMaxSeg) ? nthr : uint32_t(kMaxSeg);
+  double acc = 0.0;
+  for (uint32_t t = tid; t < Tcur; t += nthr) {
+    double mu[3], sd[3];
+    load_control(d, t, mu, sd);
+    const size_t ri = size_t(c) * d.Tcap + t;
+    acc += control_log_pdf(mu, sd, Pose{d.relx[ri], d.rely[ri], d.relth[ri]});
+  }
+  const uint32_t nf = d.nf[c];
+  const size_t fbase = size_t(c) * d.Fcap;
+  for (uint32_t f0 = 0; f0 < nf; f0 += segcap) {
+    const uint32_t nseg = (nf - f0) < segcap ? (nf - f0) : segcap;
+    uint32_t len = 0;
+    if (tid < nseg) {
+      const uint32_t f = f0 + tid;
+      const Vec2 w = act(world_pose(d, c, d.fpt[fbase + f]), Vec2{d.fex[fbase + f], d.fey[fbase + f]});
+      S.seglo[tid] = d.foff[f];
+      S.segw[tid][0] = w.x;
+      S.segw[tid][1] = w.y;
+      S.segw[tid][2] = w.x;
+      S.segw[tid][3] = w.y;
+      len = d.fcnt[fbase + f];
+    }
+    uint32_t total;
+    const uint32_t incl = block_scan_u32(len, S, total);
+    if (tid < nseg) S.segpre[tid + 1] = incl;
+    if (tid == 0) S.segpre[0] = 0;
+    __syncthreads();
+    acc += eval_segments<true>(d, c, S, nseg);
+    __syncthreads();
+  }
+  const double r = block_sum(acc, S);
+  if (tid == 0) out[c] = r;
+}
+
+__global__ void init_chains_kernel(Dev d, const uint32_t* seeds) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d.C) return;
+  uint32_t* mt = d.mt + size_t(c) * 624;
+  mt[0] = seeds[c];
+  for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + uint32_t(i);
+  d.mti[c] = 624;
+  d.nflag[c] = 0;
+  d.nsaved[c] = 0.0;
+  d.nf[c] = 0;
+  d.ll[c] = 0.0;
+  d.n_updates[c] = 0;
+  d.n_accepts[c] = 0;
+  d.n_units[c] = 0;
+  d.errflag[c] = 0;
+  if (d.trace_n) d.trace_n[c] = 0;
+  d.locx[size_t(c) * (d.Tcap + 1)] = 0.0;
+  d.locy[size_t(c) * (d.Tcap + 1)] = 0.0;
+  d.locth[size_t(c) * (d.Tcap + 1)] = 0.0;
+  d.boff[size_t(c) * d.NBcap] = BlockXf{0.0, 0.0, 1.0, 0.0};
+  d.bth[size_t(c) * d.NBcap] = 0.0;
+}
+
+__global__ void summaries_kernel(Dev d, mcmcgpu_chain_summary* out) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d.C) return;
+  out[c].log_likelihood = d.ll[c];
+  out[c].updates = uint32_t(d.n_updates[c]);
+  out[c].accepts = uint32_t(d.n_accepts[c]);
+}
+
+// Recomputes both weight trees of one chain from its current estimates (each
+// edge weight is a function of the edge's current value: mcmc_slam.hpp:240-241,
+// 262-263, 388-390).  One lane; used after importing a foreign state.
+__global__ void reweigh_kernel(Dev d, uint32_t c, uint32_t Tcur) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double* sw = d.sw + size_t(c) * d.Tcap;
+  for (uint32_t t = 0; t < Tcur; ++t) {
+    double mu[3], sd[3];
+    load_control(d, t, mu, sd);
+    const size_t ri = size_t(c) * d.Tcap + t;
+    const double lp = control_log_pdf(mu, sd, Pose{d.relx[ri], d.rely[ri], d.relth[ri]});
+    wt::push_back(sw, t, edge_weight_from_log_pdf(lp, 3.0, nullptr));
+  }
+  double* fw = d.fw + size_t(c) * d.Fcap;
+  const uint32_t nf = d.nf[c];
+  for (uint32_t f = 0; f < nf; ++f) {
+    const size_t fi = size_t(c) * d.Fcap + f;
+    const uint32_t po = d.foff[f] + d.fpar[fi];
+    const double lp = range_proposal_log_pdf(d.omu[po], d.osd[po], Vec2{d.fex[fi], d.fey[fi]});
+    wt::push_back(fw, f, edge_weight_from_log_pdf(lp, 2.0, nullptr));
+  }
+}
+
+// Scan self-test over the integer affine group (exact).
+__global__ void scan_affine_kernel(uint32_t n, int32_t p, const int32_t* a, const int32_t* b, int32_t* oa,
+                                   int32_t* ob) {
+  __shared__ Affine stage[kMaxWaves];
+  const AffineOp op{p};
+  Affine carry = op.identity();
+  for (uint32_t i0 = 0; i0 < n; i0 += blockDim.x) {
+    const uint32_t i = i0 + threadIdx.x;
+    Affine v = op.identity();
+    if (i < n) v = Affine{a[i], b[i]};
+    Affine total;
+    Affine inc = block_scan_inclusive(v, op, stage, total);
+    inc = op(carry, inc);
+    if (i < n) {
+      oa[i] = inc.a;
+      ob[i] = inc.b;
+    }
+    carry = op(carry, total);
+  }
+}
+
+}  // namespace mg
+
+#endif  // SLAM_AMD_CHAIN_KERNELS_HPP

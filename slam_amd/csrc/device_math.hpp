@@ -1,0 +1,271 @@
+// Device-side scalar building blocks of the MCMC-SLAM sampler for gfx950:
+// SE(2) poses, the two sensor/motion models, the weighted edge tree and the
+// Mersenne-Twister stream.  Everything here is straight-line fp64 code meant
+// to run in a single lane (the per-chain serial part of a Metropolis-Hastings
+// step); the data-parallel parts live in mcmcgpu.hip.
+//
+// Reference behaviour reproduced (paths relative to the reference tree):
+//   src/planar_robot/pose.hpp:67-87, position.hpp:27-35   poses and points
+//   src/planar_robot/velocity_model.hpp:37-63             control <-> pose
+//   src/planar_robot/range_bearing_model.hpp:135-176      range-only model
+//   src/utility/random.hpp:94-121,250-264                 normal sampling / log pdf
+//   src/utility/geometry.hpp:8-16                         wrap_angle
+//   src/utility/bitree.hpp:17-48,219-321                  weight tree on doubles
+//   libstdc++ 11 <random> (mt19937, generate_canonical, normal_distribution)
+#ifndef SLAM_AMD_DEVICE_MATH_HPP
+#define SLAM_AMD_DEVICE_MATH_HPP
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mg {
+
+#define MG_DEV __host__ __device__ __forceinline__
+#define MG_DEVN __host__ __device__ __noinline__
+
+constexpr double kPi = 3.14159265358979323846264338327950288;
+constexpr double kTwoPi = 2.0 * kPi;
+
+struct Vec2 {
+  double x, y;
+};
+
+struct Pose {
+  double x, y, th;
+};
+
+MG_DEV Pose pose_identity() { return Pose{0.0, 0.0, 0.0}; }
+
+// a then b:  t = a.t + R(a.th) b.t,  th = a.th + b.th  (angles are never wrapped)
+MG_DEV Pose compose(const Pose& a, const Pose& b) {
+  double s, c;
+  sincos(a.th, &s, &c);
+  return Pose{a.x + (c * b.x - s * b.y), a.y + (s * b.x + c * b.y), a.th + b.th};
+}
+
+MG_DEV Pose inverse(const Pose& a) {
+  double s, c;
+  sincos(-a.th, &s, &c);
+  const double nx = -a.x, ny = -a.y;
+  return Pose{c * nx - s * ny, s * nx + c * ny, -a.th};
+}
+
+// p acting on a point:  t + R(th) v
+MG_DEV Vec2 act(const Pose& p, const Vec2& v) {
+  double s, c;
+  sincos(p.th, &s, &c);
+  return Vec2{p.x + (c * v.x - s * v.y), p.y + (s * v.x + c * v.y)};
+}
+
+// inverse of p acting on a point:  R(-th) (v - t)
+MG_DEV Vec2 act_inverse(const Pose& p, const Vec2& v) {
+  double s, c;
+  sincos(p.th, &s, &c);
+  const double dx = v.x - p.x, dy = v.y - p.y;
+  return Vec2{c * dx + s * dy, c * dy - s * dx};
+}
+
+MG_DEV double wrap_angle(double a) {
+  a = fmod(a, kTwoPi);
+  if (a < -kPi)
+    a += kTwoPi;
+  else if (a >= kPi)
+    a -= kTwoPi;
+  return a;
+}
+
+// ---- velocity-slip control model -------------------------------------------
+// pose increment -> (arc length, turn, slip)
+MG_DEV void control_observe(const Pose& dp, double out[3]) {
+  const double r = 0.5 * (dp.x * dp.x + dp.y * dp.y) / dp.y;
+  if (isfinite(r)) {
+    const double alpha = r >= 0 ? atan2(dp.x, r - dp.y) : atan2(-dp.x, dp.y - r);
+    out[0] = r * alpha;
+    out[1] = alpha;
+    out[2] = wrap_angle(dp.th - alpha);
+  } else {
+    out[0] = dp.x;
+    out[1] = 0.0;
+    out[2] = dp.th;
+  }
+}
+
+MG_DEV Pose control_inv_observe(const double v[3]) {
+  const double s = v[0], alpha = v[1], beta = v[2], r = s / alpha;
+  if (isfinite(r)) return Pose{r * sin(alpha), r - r * cos(alpha), alpha + beta};
+  return Pose{s, 0.0, beta};
+}
+
+// log pdf of an independent 3-normal, constants subtracted term by term
+MG_DEV double normal3_log_pdf(const double mu[3], const double sd[3], const double x[3]) {
+  const double z0 = (x[0] - mu[0]) / sd[0];
+  const double z1 = (x[1] - mu[1]) / sd[1];
+  const double z2 = (x[2] - mu[2]) / sd[2];
+  const double exponent = -0.5 * (z0 * z0 + z1 * z1 + z2 * z2);
+  const double log_root_two_pi = 0.5 * log(2 * kPi);
+  const double log_det = log(sd[0]) + log(sd[1]) + log(sd[2]);
+  return exponent - 3 * log_root_two_pi - log_det;
+}
+
+// log pdf of the control model at a pose increment
+MG_DEV double control_log_pdf(const double mu[3], const double sd[3], const Pose& dp) {
+  double v[3];
+  control_observe(dp, v);
+  return normal3_log_pdf(mu, sd, v);
+}
+
+// ---- range-only observation model ------------------------------------------
+MG_DEV double range_log_pdf(double mu, double sd, double r) {
+  const double z = (r - mu) / sd;
+  const double log_root_two_pi = 0.5 * log(2 * kPi);
+  return -0.5 * (z * z) - log_root_two_pi - log(sd);
+}
+
+MG_DEV double vec_norm(const Vec2& v) { return sqrt(v.x * v.x + v.y * v.y); }
+
+// log pdf of the landmark proposal (range normal x uniform direction)
+MG_DEV double range_proposal_log_pdf(double mu, double sd, const Vec2& p) {
+  return range_log_pdf(mu, sd, vec_norm(p)) - log(2 * kPi);
+}
+
+MG_DEV Vec2 polar(double dist, double dir) { return Vec2{dist * cos(dir), dist * sin(dir)}; }
+
+MG_DEV double edge_weight_from_log_pdf(double log_pdf, double dim, double* log_weight) {
+  const double lw = log(dim) - log_pdf / dim;
+  if (log_weight) *log_weight = lw;
+  return exp(lw);
+}
+
+// ---- weight tree: Fenwick layout over doubles, bit-reproducible --------------
+// node[i] holds the sum of the values (parent(i), i], parent(i) = i & (i-1).
+// Only additions and negations are used, in the reference's exact order, so
+// totals and searched indices are identical to the CPU for identical weights.
+namespace wt {
+MG_DEV uint32_t parent(uint32_t i) { return i & (i - 1); }
+MG_DEV uint32_t next_sibling(uint32_t i) { return i + (i & (0u - i)); }
+MG_DEV uint32_t suffix_mask(uint32_t i) {
+  i |= i >> 1;
+  i |= i >> 2;
+  i |= i >> 4;
+  i |= i >> 8;
+  i |= i >> 16;
+  return i;
+}
+MG_DEV uint32_t child_containing(uint32_t p, uint32_t i) { return i & ~(suffix_mask(p ^ i) >> 1); }
+
+MG_DEV double sum_to_ancestor(const double* node, uint32_t i, uint32_t ancestor) {
+  double result = 0.0;
+  for (; i != ancestor; i = parent(i)) result = node[i] + result;
+  return result;
+}
+MG_DEV double total(const double* node, uint32_t n) {
+  if (n == 0) return 0.0;
+  return node[0] + sum_to_ancestor(node, n - 1, 0);
+}
+MG_DEV double node_value_for(const double* node, uint32_t i, double v) {
+  if (i == 0) return v;
+  return sum_to_ancestor(node, i - 1, parent(i)) + v;
+}
+MG_DEV double get(const double* node, uint32_t i) {
+  if (i == 0) return node[0];
+  return -sum_to_ancestor(node, i - 1, parent(i)) + node[i];
+}
+MG_DEV void push_back(double* node, uint32_t n, double v) { node[n] = node_value_for(node, n, v); }
+MG_DEV void set(double* node, uint32_t n, uint32_t i, double v) {
+  double new_value = node_value_for(node, i, v);
+  if (i > 0)
+    for (uint32_t next; (next = next_sibling(i)) < n; i = next) {
+      double delta = new_value + (-node[i]);
+      node[i] = new_value;
+      const uint32_t next_parent = parent(next);
+      while ((i = parent(i)) != next_parent) delta = node[i] + delta + (-node[i]);
+      new_value = delta + node[next];
+    }
+  node[i] = new_value;
+}
+// index k with prefix(k) <= value < prefix(k+1); may return n when value >= total
+MG_DEV uint32_t search(const double* node, uint32_t n, double value) {
+  if (n == 0 || value < node[0]) return 0;
+  uint32_t lo = 0, hi = n;
+  double origin = node[0];
+  while (lo + 1 < hi) {
+    const uint32_t mid = child_containing(lo, hi - 1);
+    if (value < origin + node[mid])
+      hi = mid;
+    else {
+      lo = mid;
+      origin += node[lo];
+    }
+  }
+  return hi;
+}
+}  // namespace wt
+
+// ---- random stream -----------------------------------------------------------
+// 32-bit Mersenne Twister with libstdc++'s uniform and normal transforms on top;
+// the state lives in LDS while a chain kernel runs and is used by one lane.
+struct RngState {
+  uint32_t mt[624];
+  int32_t idx;
+  int32_t has_saved;
+  double saved;
+};
+
+MG_DEV void rng_seed(RngState& r, uint32_t seed) {
+  r.mt[0] = seed;
+  for (int i = 1; i < 624; ++i) r.mt[i] = 1812433253u * (r.mt[i - 1] ^ (r.mt[i - 1] >> 30)) + uint32_t(i);
+  r.idx = 624;
+  r.has_saved = 0;
+  r.saved = 0.0;
+}
+
+MG_DEVN void rng_refill(RngState& r) {
+  for (int i = 0; i < 624; ++i) {
+    const int i1 = (i + 1 == 624) ? 0 : i + 1;
+    const int im = (i + 397 >= 624) ? i + 397 - 624 : i + 397;
+    const uint32_t y = (r.mt[i] & 0x80000000u) | (r.mt[i1] & 0x7fffffffu);
+    r.mt[i] = r.mt[im] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+  }
+  r.idx = 0;
+}
+
+MG_DEV uint32_t rng_next(RngState& r) {
+  if (r.idx >= 624) rng_refill(r);
+  uint32_t y = r.mt[r.idx++];
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= y >> 18;
+  return y;
+}
+
+// generate_canonical<double,53>: (lo + hi * 2^32) / 2^64, kept below 1
+MG_DEV double rng_uniform(RngState& r) {
+  const double lo = double(rng_next(r));
+  const double hi = double(rng_next(r));
+  double ret = (lo + hi * 4294967296.0) / 18446744073709551616.0;
+  if (ret >= 1.0) ret = 0x1.fffffffffffffp-1;
+  return ret;
+}
+
+// Marsaglia polar method; the second variate is kept for the next call
+MG_DEV double rng_normal(RngState& r) {
+  if (r.has_saved) {
+    r.has_saved = 0;
+    return r.saved;
+  }
+  double x, y, r2;
+  do {
+    x = 2.0 * rng_uniform(r) - 1.0;
+    y = 2.0 * rng_uniform(r) - 1.0;
+    r2 = x * x + y * y;
+  } while (r2 > 1.0 || r2 == 0.0);
+  const double mult = sqrt(-2 * log(r2) / r2);
+  r.saved = x * mult;
+  r.has_saved = 1;
+  return y * mult;
+}
+
+}  // namespace mg
+
+#endif  // SLAM_AMD_DEVICE_MATH_HPP

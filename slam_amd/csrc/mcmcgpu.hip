@@ -1,0 +1,653 @@
+// Host side of the C ABI declared in include/mcmcgpu.h: device memory layout,
+// problem flattening (per-landmark CSR + arrival index) and kernel launches.
+// All device memory is allocated once in mcmcgpu_create for the capacities the
+// caller states; no other entry point allocates device memory.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "chain_kernels.hpp"
+
+using namespace mg;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct EventPair {
+  hipEvent_t start, stop;
+};
+
+}  // namespace
+
+struct mcmcgpu_ctx {
+  mcmcgpu_config cfg{};
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  Dev d{};
+  std::vector<void*> allocations;
+  Pose* scan_tot = nullptr;  // [C][NBcap] tile totals of the rebuild scan
+  uint32_t* seed_stage = nullptr;  // [C]
+  double* scratch = nullptr;  // readout staging: max(3*(Tcap+1), ...) doubles
+  size_t scratch_doubles = 0;
+  uint32_t nthreads = 256;
+  // host-side bookkeeping
+  uint32_t chains = 0;
+  bool problem_loaded = false;
+  uint32_t next_timestep = 0;  // first timestep the chains have not processed
+  std::vector<EventPair> timings;
+  std::vector<EventPair> free_events;
+  std::string error;
+};
+
+namespace {
+
+int fail(mcmcgpu_handle h, int code, const std::string& msg) {
+  if (h)
+    h->error = msg;
+  else
+    g_create_error = msg;
+  return code;
+}
+
+#define HIP_TRY(h, expr)                                                                    \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail(h, MCMCGPU_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+template <class T>
+int dev_alloc(mcmcgpu_handle h, T** out, size_t count) {
+  void* p = nullptr;
+  const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess)
+    return fail(h, MCMCGPU_ERR_HIP, "hipMalloc of " + std::to_string(bytes) + " bytes: " + hipGetErrorString(e));
+  e = hipMemsetAsync(p, 0, bytes, h->stream);
+  if (e != hipSuccess) return fail(h, MCMCGPU_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e));
+  h->allocations.push_back(p);
+  *out = static_cast<T*>(p);
+  return 0;
+}
+
+uint32_t edges_grown(const mcmcgpu_ctx* h) { return h->next_timestep == 0 ? 0 : h->next_timestep - 1; }
+
+bool is_pow2(uint32_t v) { return v && !(v & (v - 1)); }
+
+int check_device_flags(mcmcgpu_handle h) {
+  std::vector<uint32_t> flags(h->chains);
+  if (h->chains == 0) return 0;
+  HIP_TRY(h, hipMemcpyAsync(flags.data(), h->d.errflag, sizeof(uint32_t) * h->chains, hipMemcpyDeviceToHost,
+                            h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  for (uint32_t c = 0; c < h->chains; ++c)
+    if (flags[c])
+      return fail(h, MCMCGPU_ERR_DEVICE_FAULT,
+                  "chain " + std::to_string(c) + " stopped: edge selection did not terminate");
+  return 0;
+}
+
+int rebuild_impl(mcmcgpu_handle h) {
+  const uint32_t Tcur = edges_grown(h);
+  const uint32_t nblocks = (Tcur >> h->d.sh) + 1;
+  hipLaunchKernelGGL(scan_local_kernel, dim3(nblocks, h->chains), dim3(1u << h->d.sh), 0, h->stream, h->d, Tcur,
+                     h->scan_tot);
+  hipLaunchKernelGGL(scan_offsets_kernel, dim3(h->chains), dim3(256), 0, h->stream, h->d, nblocks, h->scan_tot);
+  HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mcmcgpu_last_error(mcmcgpu_handle h) { return h ? h->error.c_str() : g_create_error.c_str(); }
+
+int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out) {
+  if (!cfg || !out) return fail(nullptr, MCMCGPU_ERR_ARGUMENT, "null argument");
+  if (cfg->max_chains == 0) return fail(nullptr, MCMCGPU_ERR_ARGUMENT, "max_chains must be positive");
+  const uint32_t sh = cfg->block_shift ? cfg->block_shift : 8;
+  if (sh < 6 || sh > 10) return fail(nullptr, MCMCGPU_ERR_ARGUMENT, "block_shift must be in [6, 10]");
+  const uint32_t nthr = cfg->threads_per_chain ? cfg->threads_per_chain : 256;
+  if (nthr < 64 || nthr > 1024 || !is_pow2(nthr))
+    return fail(nullptr, MCMCGPU_ERR_ARGUMENT, "threads_per_chain must be a power of two in [64, 1024]");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, MCMCGPU_ERR_HIP, "no HIP device available (this library has no CPU path)");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, MCMCGPU_ERR_ARGUMENT, "device ordinal out of range");
+  hipError_t e = hipSetDevice(cfg->device);
+  if (e != hipSuccess) return fail(nullptr, MCMCGPU_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+
+  mcmcgpu_handle h = new mcmcgpu_ctx();
+  h->cfg = *cfg;
+  h->nthreads = nthr;
+  if (cfg->stream) {
+    h->stream = static_cast<hipStream_t>(cfg->stream);
+  } else {
+    e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      delete h;
+      return fail(nullptr, MCMCGPU_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    h->own_stream = true;
+  }
+  Dev& d = h->d;
+  d.Tcap = std::max<uint32_t>(cfg->max_timesteps, 1);
+  d.Fcap = std::max<uint32_t>(cfg->max_features, 1);
+  d.Ncap = std::max<uint32_t>(cfg->max_observations, 1);
+  d.C = 0;
+  d.sh = sh;
+  d.NBcap = (d.Tcap >> sh) + 1;
+  d.uniform_first = cfg->feature_uniform_first ? 1 : 0;
+  d.trace_cap = cfg->trace_capacity;
+  const size_t C = cfg->max_chains;
+  int rc = 0;
+#define ALLOC(ptr, count)                                                         \
+  do {                                                                            \
+    if (!rc) rc = dev_alloc(h, const_cast<std::remove_const_t<std::remove_pointer_t<decltype(ptr)>>**>(&(ptr)), count); \
+  } while (0)
+  ALLOC(d.cmu, 3 * size_t(d.Tcap));
+  ALLOC(d.csd, 3 * size_t(d.Tcap));
+  ALLOC(d.foff, size_t(d.Fcap) + 1);
+  ALLOC(d.ot, d.Ncap);
+  ALLOC(d.omu, d.Ncap);
+  ALLOC(d.osd, d.Ncap);
+  ALLOC(d.ofeat, d.Ncap);
+  ALLOC(d.toff, size_t(d.Tcap) + 2);
+  ALLOC(d.tobs, d.Ncap);
+  ALLOC(d.ffirst, d.Fcap);
+  ALLOC(d.init_u, d.Fcap);
+  ALLOC(d.relx, C * d.Tcap);
+  ALLOC(d.rely, C * d.Tcap);
+  ALLOC(d.relth, C * d.Tcap);
+  ALLOC(d.locx, C * (size_t(d.Tcap) + 1));
+  ALLOC(d.locy, C * (size_t(d.Tcap) + 1));
+  ALLOC(d.locth, C * (size_t(d.Tcap) + 1));
+  ALLOC(d.boff, C * d.NBcap);
+  ALLOC(d.bth, C * d.NBcap);
+  ALLOC(d.sw, C * d.Tcap);
+  ALLOC(d.fw, C * d.Fcap);
+  ALLOC(d.fex, C * d.Fcap);
+  ALLOC(d.fey, C * d.Fcap);
+  ALLOC(d.fpar, C * d.Fcap);
+  ALLOC(d.fcnt, C * d.Fcap);
+  ALLOC(d.fpt, C * d.Fcap);
+  ALLOC(d.flast, C * d.Fcap);
+  ALLOC(d.nf, C);
+  ALLOC(d.ll, C);
+  ALLOC(d.mt, C * 624);
+  ALLOC(d.mti, C);
+  ALLOC(d.nflag, C);
+  ALLOC(d.nsaved, C);
+  ALLOC(d.n_updates, C);
+  ALLOC(d.n_accepts, C);
+  ALLOC(d.n_units, C);
+  ALLOC(d.errflag, C);
+  ALLOC(d.trace_n, C);
+  if (d.trace_cap) ALLOC(d.trace, C * d.trace_cap);
+  ALLOC(h->scan_tot, C * d.NBcap);
+  ALLOC(h->seed_stage, C);
+  h->scratch_doubles = 5 * (size_t(d.Tcap) + 1) + 4 * size_t(d.Fcap) + 16;
+  ALLOC(h->scratch, h->scratch_doubles);
+#undef ALLOC
+  if (rc) {
+    g_create_error = h->error;
+    mcmcgpu_destroy(h);
+    return rc;
+  }
+  d.n_init_u = 0;
+  *out = h;
+  return 0;
+}
+
+void mcmcgpu_destroy(mcmcgpu_handle h) {
+  if (!h) return;
+  (void)hipSetDevice(h->cfg.device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (auto& ev : h->timings) {
+    (void)hipEventDestroy(ev.start);
+    (void)hipEventDestroy(ev.stop);
+  }
+  for (auto& ev : h->free_events) {
+    (void)hipEventDestroy(ev.start);
+    (void)hipEventDestroy(ev.stop);
+  }
+  for (void* p : h->allocations) (void)hipFree(p);
+  if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int mcmcgpu_upload_problem(mcmcgpu_handle h, uint32_t T, const double* ctrl_mean, const double* ctrl_stddev,
+                           uint32_t N, const uint32_t* obs_timestep, const uint32_t* obs_feature,
+                           const double* obs_mean, const double* obs_stddev, uint32_t F) {
+  if (!h) return MCMCGPU_ERR_ARGUMENT;
+  Dev& d = h->d;
+  if (T > h->cfg.max_timesteps || N > h->cfg.max_observations || F > h->cfg.max_features)
+    return fail(h, MCMCGPU_ERR_CAPACITY, "problem exceeds the capacities given to mcmcgpu_create");
+  if ((T && (!ctrl_mean || !ctrl_stddev)) || (N && (!obs_timestep || !obs_feature || !obs_mean || !obs_stddev)))
+    return fail(h, MCMCGPU_ERR_ARGUMENT, "null problem array");
+  if (T + 1 < h->next_timestep) return fail(h, MCMCGPU_ERR_STATE, "problem shorter than what the chains have processed");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+
+  // controls: [t][3] -> [3][Tcap]
+  std::vector<double> cmu(3 * size_t(d.Tcap), 0.0), csd(3 * size_t(d.Tcap), 1.0);
+  for (uint32_t t = 0; t < T; ++t)
+    for (int i = 0; i < 3; ++i) {
+      cmu[size_t(i) * d.Tcap + t] = ctrl_mean[3 * size_t(t) + i];
+      csd[size_t(i) * d.Tcap + t] = ctrl_stddev[3 * size_t(t) + i];
+    }
+  // readings: arrival order -> landmark-major, time-sorted inside a landmark
+  std::vector<uint32_t> foff(size_t(F) + 1, 0), toff(size_t(T) + 2, 0);
+  uint32_t seen = 0;
+  for (uint32_t i = 0; i < N; ++i) {
+    const uint32_t f = obs_feature[i], t = obs_timestep[i];
+    if (t > T) return fail(h, MCMCGPU_ERR_ARGUMENT, "reading " + std::to_string(i) + " has a timestep beyond T");
+    if (i && t < obs_timestep[i - 1]) return fail(h, MCMCGPU_ERR_ARGUMENT, "readings are not in arrival order");
+    if (f > seen || f >= F)
+      return fail(h, MCMCGPU_ERR_ARGUMENT, "landmark indices must be dense and numbered by first appearance");
+    if (f == seen) ++seen;
+    if (!(obs_stddev[i] > 0)) return fail(h, MCMCGPU_ERR_ARGUMENT, "non-positive reading stddev");
+    ++foff[f + 1];
+    ++toff[t + 1];
+  }
+  if (seen != F) return fail(h, MCMCGPU_ERR_ARGUMENT, "F does not match the landmarks that appear in the readings");
+  for (uint32_t f = 0; f < F; ++f) foff[f + 1] += foff[f];
+  for (uint32_t t = 0; t <= T; ++t) toff[t + 1] += toff[t];
+  std::vector<uint32_t> fill(foff.begin(), foff.end() - 1), ot(N), ofeat(N), tobs(N), ffirst(F, 0);
+  std::vector<double> omu(N), osd(N);
+  for (uint32_t i = 0; i < N; ++i) {
+    const uint32_t f = obs_feature[i];
+    const uint32_t pos = fill[f]++;
+    if (pos > foff[f] && ot[pos - 1] >= obs_timestep[i])
+      return fail(h, MCMCGPU_ERR_ARGUMENT, "a landmark has two readings at one timestep");
+    if (pos == foff[f]) ffirst[f] = obs_timestep[i];
+    ot[pos] = obs_timestep[i];
+    omu[pos] = obs_mean[i];
+    osd[pos] = obs_stddev[i];
+    ofeat[pos] = f;
+    tobs[i] = pos;  // arrivals are already grouped by timestep, in order
+  }
+  auto up = [&](const void* dst, const void* src, size_t bytes) {
+    return bytes ? hipMemcpyAsync(const_cast<void*>(dst), src, bytes, hipMemcpyHostToDevice, h->stream) : hipSuccess;
+  };
+  HIP_TRY(h, up(d.cmu, cmu.data(), cmu.size() * sizeof(double)));
+  HIP_TRY(h, up(d.csd, csd.data(), csd.size() * sizeof(double)));
+  HIP_TRY(h, up(d.foff, foff.data(), foff.size() * sizeof(uint32_t)));
+  HIP_TRY(h, up(d.toff, toff.data(), toff.size() * sizeof(uint32_t)));
+  HIP_TRY(h, up(d.ot, ot.data(), size_t(N) * sizeof(uint32_t)));
+  HIP_TRY(h, up(d.ofeat, ofeat.data(), size_t(N) * sizeof(uint32_t)));
+  HIP_TRY(h, up(d.tobs, tobs.data(), size_t(N) * sizeof(uint32_t)));
+  HIP_TRY(h, up(d.omu, omu.data(), size_t(N) * sizeof(double)));
+  HIP_TRY(h, up(d.osd, osd.data(), size_t(N) * sizeof(double)));
+  HIP_TRY(h, up(d.ffirst, ffirst.data(), size_t(F) * sizeof(uint32_t)));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));  // host staging vectors die here
+  d.T = T;
+  d.N = N;
+  d.F = F;
+  h->problem_loaded = true;
+  return 0;
+}
+
+int mcmcgpu_init_chains(mcmcgpu_handle h, uint32_t C, const uint32_t* seeds, const double* init_uniforms,
+                        uint32_t n_init_uniforms) {
+  if (!h || !seeds) return fail(h, MCMCGPU_ERR_ARGUMENT, "null argument");
+  if (C == 0 || C > h->cfg.max_chains) return fail(h, MCMCGPU_ERR_CAPACITY, "chain count out of range");
+  if (init_uniforms && n_init_uniforms > h->d.Fcap) return fail(h, MCMCGPU_ERR_CAPACITY, "too many initialiser draws");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  Dev& d = h->d;
+  d.C = C;
+  h->chains = C;
+  h->next_timestep = 0;
+  uint32_t* dseeds = h->seed_stage;
+  HIP_TRY(h, hipMemcpyAsync(dseeds, seeds, size_t(C) * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+  d.n_init_u = 0;
+  if (init_uniforms && n_init_uniforms) {
+    HIP_TRY(h, hipMemcpyAsync(const_cast<double*>(d.init_u), init_uniforms, size_t(n_init_uniforms) * sizeof(double),
+                              hipMemcpyHostToDevice, h->stream));
+    d.n_init_u = n_init_uniforms;
+  }
+  hipLaunchKernelGGL(init_chains_kernel, dim3((C + 255) / 256), dim3(256), 0, h->stream, d, dseeds);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int mcmcgpu_advance(mcmcgpu_handle h, uint32_t upto, uint32_t steps_per_timestep, uint32_t end_steps) {
+  if (!h) return MCMCGPU_ERR_ARGUMENT;
+  if (!h->problem_loaded || h->chains == 0) return fail(h, MCMCGPU_ERR_STATE, "upload a problem and init chains first");
+  if (upto > h->d.T) return fail(h, MCMCGPU_ERR_ARGUMENT, "timestep beyond the uploaded problem");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  const bool grow = upto + 1 > h->next_timestep;
+  if (!grow && end_steps == 0) return 0;
+  EventPair ev;
+  if (!h->free_events.empty()) {
+    ev = h->free_events.back();
+    h->free_events.pop_back();
+  } else {
+    HIP_TRY(h, hipEventCreate(&ev.start));
+    HIP_TRY(h, hipEventCreate(&ev.stop));
+  }
+  HIP_TRY(h, hipEventRecord(ev.start, h->stream));
+  hipLaunchKernelGGL(advance_kernel, dim3(h->chains), dim3(h->nthreads), 0, h->stream, h->d, h->next_timestep,
+                     edges_grown(h), upto, steps_per_timestep, end_steps, grow ? 1u : 0u);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipEventRecord(ev.stop, h->stream));
+  h->timings.push_back(ev);
+  if (grow) h->next_timestep = upto + 1;
+  return 0;
+}
+
+int mcmcgpu_grow(mcmcgpu_handle h, uint32_t upto) { return mcmcgpu_advance(h, upto, 0, 0); }
+
+int mcmcgpu_run(mcmcgpu_handle h, uint32_t steps) {
+  if (!h) return MCMCGPU_ERR_ARGUMENT;
+  if (h->next_timestep == 0) return fail(h, MCMCGPU_ERR_STATE, "chains have not processed timestep 0 yet");
+  return mcmcgpu_advance(h, h->next_timestep - 1, 0, steps);
+}
+
+int mcmcgpu_eval_llr(mcmcgpu_handle h, uint32_t chain, int kind, uint32_t index, const double proposed[3],
+                     double* out) {
+  if (!h || !proposed || !out) return fail(h, MCMCGPU_ERR_ARGUMENT, "null argument");
+  if (chain >= h->chains) return fail(h, MCMCGPU_ERR_ARGUMENT, "chain out of range");
+  if (kind == MCMCGPU_STATE_EDGE) {
+    if (index >= edges_grown(h)) return fail(h, MCMCGPU_ERR_ARGUMENT, "state edge out of range");
+  } else if (kind == MCMCGPU_FEATURE_EDGE) {
+    if (index >= h->d.F) return fail(h, MCMCGPU_ERR_ARGUMENT, "landmark out of range");
+  } else {
+    return fail(h, MCMCGPU_ERR_ARGUMENT, "unknown edge kind");
+  }
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  if (kind == MCMCGPU_FEATURE_EDGE) {
+    uint32_t nf = 0;
+    HIP_TRY(h, hipMemcpyAsync(&nf, h->d.nf + chain, sizeof nf, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (index >= nf) return fail(h, MCMCGPU_ERR_ARGUMENT, "landmark not yet observed by this chain");
+  }
+  hipLaunchKernelGGL(eval_kernel, dim3(1), dim3(h->nthreads), 0, h->stream, h->d, chain, kind, index, proposed[0],
+                     proposed[1], proposed[2], edges_grown(h), h->scratch);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemcpyAsync(out, h->scratch, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int mcmcgpu_commit(mcmcgpu_handle h, uint32_t chain, int kind, uint32_t index, const double proposed[3],
+                   double new_weight, double log_ratio) {
+  if (!h || !proposed) return fail(h, MCMCGPU_ERR_ARGUMENT, "null argument");
+  if (chain >= h->chains) return fail(h, MCMCGPU_ERR_ARGUMENT, "chain out of range");
+  if (kind == MCMCGPU_STATE_EDGE) {
+    if (index >= edges_grown(h)) return fail(h, MCMCGPU_ERR_ARGUMENT, "state edge out of range");
+  } else if (kind == MCMCGPU_FEATURE_EDGE) {
+    uint32_t nf = 0;
+    HIP_TRY(h, hipMemcpyAsync(&nf, h->d.nf + chain, sizeof nf, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (index >= nf) return fail(h, MCMCGPU_ERR_ARGUMENT, "landmark out of range");
+  } else {
+    return fail(h, MCMCGPU_ERR_ARGUMENT, "unknown edge kind");
+  }
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  hipLaunchKernelGGL(commit_kernel, dim3(1), dim3(h->nthreads), 0, h->stream, h->d, chain, kind, index,
+                     proposed[0], proposed[1], proposed[2], new_weight, log_ratio, edges_grown(h));
+  HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
+int mcmcgpu_rebuild(mcmcgpu_handle h) {
+  if (!h) return MCMCGPU_ERR_ARGUMENT;
+  if (h->chains == 0) return fail(h, MCMCGPU_ERR_STATE, "no chains");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  return rebuild_impl(h);
+}
+
+int mcmcgpu_get_log_likelihood(mcmcgpu_handle h, double* out) {
+  if (!h || !out) return fail(h, MCMCGPU_ERR_ARGUMENT, "null argument");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  HIP_TRY(h, hipMemcpyAsync(out, h->d.ll, sizeof(double) * h->chains, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return check_device_flags(h);
+}
+
+int mcmcgpu_full_log_likelihood(mcmcgpu_handle h, double* out) {
+  if (!h || !out) return fail(h, MCMCGPU_ERR_ARGUMENT, "null argument");
+  if (h->chains == 0) return fail(h, MCMCGPU_ERR_STATE, "no chains");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  double* dout = nullptr;
+  // the per-chain results go to the tile-total buffer of the rebuild scan (idle here)
+  dout = reinterpret_cast<double*>(h->scan_tot);
+  hipLaunchKernelGGL(full_ll_kernel, dim3(h->chains), dim3(h->nthreads), 0, h->stream, h->d, edges_grown(h), dout);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemcpyAsync(out, dout, sizeof(double) * h->chains, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int mcmcgpu_get_dims(mcmcgpu_handle h, uint32_t* timesteps, uint32_t* features, uint32_t* chains) {
+  if (!h) return MCMCGPU_ERR_ARGUMENT;
+  if (timesteps) *timesteps = edges_grown(h);
+  if (chains) *chains = h->chains;
+  if (features) {
+    *features = 0;
+    if (h->chains) {
+      HIP_TRY(h, hipSetDevice(h->cfg.device));
+      HIP_TRY(h, hipMemcpyAsync(features, h->d.nf, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+  }
+  return 0;
+}
+
+int mcmcgpu_get_state(mcmcgpu_handle h, uint32_t chain, double* rel_poses, double* cum_poses,
+                      uint32_t* feat_parent, double* feat_estimate, double* feat_world, double* state_weights,
+                      double* feat_weights) {
+  if (!h) return MCMCGPU_ERR_ARGUMENT;
+  if (chain >= h->chains) return fail(h, MCMCGPU_ERR_ARGUMENT, "chain out of range");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  const Dev& d = h->d;
+  const uint32_t T = edges_grown(h);
+  uint32_t nf = 0;
+  HIP_TRY(h, hipMemcpyAsync(&nf, d.nf + chain, sizeof nf, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  auto down = [&](void* dst, const void* src, size_t bytes) {
+    return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream) : hipSuccess;
+  };
+  if (rel_poses) {
+    std::vector<double> x(T), y(T), th(T);
+    HIP_TRY(h, down(x.data(), d.relx + size_t(chain) * d.Tcap, sizeof(double) * T));
+    HIP_TRY(h, down(y.data(), d.rely + size_t(chain) * d.Tcap, sizeof(double) * T));
+    HIP_TRY(h, down(th.data(), d.relth + size_t(chain) * d.Tcap, sizeof(double) * T));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (uint32_t t = 0; t < T; ++t) {
+      rel_poses[3 * size_t(t)] = x[t];
+      rel_poses[3 * size_t(t) + 1] = y[t];
+      rel_poses[3 * size_t(t) + 2] = th[t];
+    }
+  }
+  if (cum_poses) {
+    hipLaunchKernelGGL(materialize_kernel, dim3((T + 1 + 255) / 256), dim3(256), 0, h->stream, d, chain, T,
+                       h->scratch);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, down(cum_poses, h->scratch, sizeof(double) * 3 * (size_t(T) + 1)));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  }
+  if (feat_world || state_weights || feat_weights) {
+    double* dworld = h->scratch;                  // [2*Fcap]
+    double* dfw = dworld + 2 * size_t(d.Fcap);    // [Fcap]
+    double* dsw = dfw + size_t(d.Fcap);           // [Tcap]
+    const uint32_t n = std::max(T, nf);
+    if (n) {
+      hipLaunchKernelGGL(readout_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, d, chain, T, dworld, dsw,
+                         dfw);
+      HIP_TRY(h, hipGetLastError());
+    }
+    if (feat_world) HIP_TRY(h, down(feat_world, dworld, sizeof(double) * 2 * nf));
+    if (feat_weights) HIP_TRY(h, down(feat_weights, dfw, sizeof(double) * nf));
+    if (state_weights) HIP_TRY(h, down(state_weights, dsw, sizeof(double) * T));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  }
+  if (feat_parent) {
+    HIP_TRY(h, down(feat_parent, d.fpt + size_t(chain) * d.Fcap, sizeof(uint32_t) * nf));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  }
+  if (feat_estimate) {
+    std::vector<double> x(nf), y(nf);
+    HIP_TRY(h, down(x.data(), d.fex + size_t(chain) * d.Fcap, sizeof(double) * nf));
+    HIP_TRY(h, down(y.data(), d.fey + size_t(chain) * d.Fcap, sizeof(double) * nf));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (uint32_t f = 0; f < nf; ++f) {
+      feat_estimate[2 * size_t(f)] = x[f];
+      feat_estimate[2 * size_t(f) + 1] = y[f];
+    }
+  }
+  return 0;
+}
+
+int mcmcgpu_get_counters(mcmcgpu_handle h, uint64_t* updates, uint64_t* accepts, uint64_t* units) {
+  if (!h) return MCMCGPU_ERR_ARGUMENT;
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  const size_t bytes = sizeof(uint64_t) * h->chains;
+  if (updates) HIP_TRY(h, hipMemcpyAsync(updates, h->d.n_updates, bytes, hipMemcpyDeviceToHost, h->stream));
+  if (accepts) HIP_TRY(h, hipMemcpyAsync(accepts, h->d.n_accepts, bytes, hipMemcpyDeviceToHost, h->stream));
+  if (units) HIP_TRY(h, hipMemcpyAsync(units, h->d.n_units, bytes, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int mcmcgpu_get_trace(mcmcgpu_handle h, uint32_t chain, mcmcgpu_step_record* out, uint32_t capacity,
+                      uint32_t* count) {
+  if (!h || !count) return fail(h, MCMCGPU_ERR_ARGUMENT, "null argument");
+  if (chain >= h->chains) return fail(h, MCMCGPU_ERR_ARGUMENT, "chain out of range");
+  if (!h->d.trace) return fail(h, MCMCGPU_ERR_STATE, "handle was created without a trace");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  uint32_t n = 0;
+  HIP_TRY(h, hipMemcpyAsync(&n, h->d.trace_n + chain, sizeof n, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  n = std::min(n, h->d.trace_cap);
+  n = std::min(n, capacity);
+  if (n && out) {
+    HIP_TRY(h, hipMemcpyAsync(out, h->d.trace + size_t(chain) * h->d.trace_cap, sizeof(mcmcgpu_step_record) * n,
+                              hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  }
+  *count = n;
+  return 0;
+}
+
+int mcmcgpu_write_summaries(mcmcgpu_handle h, void* dev_out) {
+  if (!h || !dev_out) return fail(h, MCMCGPU_ERR_ARGUMENT, "null argument");
+  if (h->chains == 0) return fail(h, MCMCGPU_ERR_STATE, "no chains");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  hipLaunchKernelGGL(summaries_kernel, dim3((h->chains + 255) / 256), dim3(256), 0, h->stream, h->d,
+                     static_cast<mcmcgpu_chain_summary*>(dev_out));
+  HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
+int mcmcgpu_export_state(mcmcgpu_handle h, uint32_t chain, void* dev_out) {
+  if (!h || !dev_out) return fail(h, MCMCGPU_ERR_ARGUMENT, "null argument");
+  if (chain >= h->chains) return fail(h, MCMCGPU_ERR_ARGUMENT, "chain out of range");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  const Dev& d = h->d;
+  const size_t T = edges_grown(h), F = d.F;
+  double* o = static_cast<double*>(dev_out);
+  auto cp = [&](double* dst, const double* src, size_t n) {
+    return n ? hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToDevice, h->stream) : hipSuccess;
+  };
+  HIP_TRY(h, cp(o, d.relx + size_t(chain) * d.Tcap, T));
+  HIP_TRY(h, cp(o + T, d.rely + size_t(chain) * d.Tcap, T));
+  HIP_TRY(h, cp(o + 2 * T, d.relth + size_t(chain) * d.Tcap, T));
+  HIP_TRY(h, cp(o + 3 * T, d.fex + size_t(chain) * d.Fcap, F));
+  HIP_TRY(h, cp(o + 3 * T + F, d.fey + size_t(chain) * d.Fcap, F));
+  return 0;
+}
+
+int mcmcgpu_import_state(mcmcgpu_handle h, uint32_t chain, const void* dev_in, double log_likelihood) {
+  if (!h || !dev_in) return fail(h, MCMCGPU_ERR_ARGUMENT, "null argument");
+  if (chain >= h->chains) return fail(h, MCMCGPU_ERR_ARGUMENT, "chain out of range");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  Dev& d = h->d;
+  const size_t T = edges_grown(h), F = d.F;
+  const double* in = static_cast<const double*>(dev_in);
+  auto cp = [&](double* dst, const double* src, size_t n) {
+    return n ? hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToDevice, h->stream) : hipSuccess;
+  };
+  HIP_TRY(h, cp(d.relx + size_t(chain) * d.Tcap, in, T));
+  HIP_TRY(h, cp(d.rely + size_t(chain) * d.Tcap, in + T, T));
+  HIP_TRY(h, cp(d.relth + size_t(chain) * d.Tcap, in + 2 * T, T));
+  HIP_TRY(h, cp(d.fex + size_t(chain) * d.Fcap, in + 3 * T, F));
+  HIP_TRY(h, cp(d.fey + size_t(chain) * d.Fcap, in + 3 * T + F, F));
+  HIP_TRY(h, hipMemcpyAsync(d.ll + chain, &log_likelihood, sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  hipLaunchKernelGGL(reweigh_kernel, dim3(1), dim3(64), 0, h->stream, d, chain, uint32_t(T));
+  HIP_TRY(h, hipGetLastError());
+  return rebuild_impl(h);
+}
+
+int mcmcgpu_sync(mcmcgpu_handle h) {
+  if (!h) return MCMCGPU_ERR_ARGUMENT;
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return check_device_flags(h);
+}
+
+int mcmcgpu_kernel_time(mcmcgpu_handle h, double* avg_ms, uint32_t* launches) {
+  if (!h) return MCMCGPU_ERR_ARGUMENT;
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  double total = 0.0;
+  for (auto& ev : h->timings) {
+    float ms = 0.f;
+    HIP_TRY(h, hipEventElapsedTime(&ms, ev.start, ev.stop));
+    total += ms;
+    h->free_events.push_back(ev);
+  }
+  const uint32_t n = uint32_t(h->timings.size());
+  h->timings.clear();
+  if (avg_ms) *avg_ms = n ? total / n : 0.0;
+  if (launches) *launches = n;
+  return 0;
+}
+
+void mcmcgpu_seed_sequence(uint32_t seed, uint32_t n, uint32_t* out) {
+  RngState r;
+  rng_seed(r, seed);
+  for (uint32_t i = 0; i < n; ++i) out[i] = rng_next(r);
+}
+
+void mcmcgpu_uniform_sequence(uint32_t seed, uint32_t n, double* out) {
+  RngState r;
+  rng_seed(r, seed);
+  for (uint32_t i = 0; i < n; ++i) out[i] = rng_uniform(r);
+}
+
+int mcmcgpu_selftest_scan(int32_t device, uint32_t n, int32_t p, const int32_t* a, const int32_t* b, int32_t* out_a,
+                          int32_t* out_b) {
+  if (!a || !b || !out_a || !out_b || p <= 1) return fail(nullptr, MCMCGPU_ERR_ARGUMENT, "bad argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+    return fail(nullptr, MCMCGPU_ERR_HIP, "no such HIP device");
+  mcmcgpu_handle h = nullptr;
+  HIP_TRY(h, hipSetDevice(device));
+  int32_t* buf = nullptr;
+  HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&buf), sizeof(int32_t) * 4 * std::max<uint32_t>(n, 1)));
+  int32_t *da = buf, *db = buf + n, *oa = buf + 2 * size_t(n), *ob = buf + 3 * size_t(n);
+  hipError_t e = hipMemcpy(da, a, sizeof(int32_t) * n, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(db, b, sizeof(int32_t) * n, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(scan_affine_kernel, dim3(1), dim3(256), 0, nullptr, n, p, da, db, oa, ob);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(out_a, oa, sizeof(int32_t) * n, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(out_b, ob, sizeof(int32_t) * n, hipMemcpyDeviceToHost);
+  (void)hipFree(buf);
+  if (e != hipSuccess) return fail(nullptr, MCMCGPU_ERR_HIP, std::string("scan self-test: ") + hipGetErrorString(e));
+  return 0;
+}
+
+}  // extern "C"

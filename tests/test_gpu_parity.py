@@ -1,0 +1,246 @@
+"""GPU parity: the HIP path through the C ABI against the CPU oracle on the same
+seeded inputs.  Bars: edge kinds, edge indices and accept bits identical; chain
+log likelihoods and cumulative poses within 1e-9 relative (fp64)."""
+import numpy as np
+import pytest
+
+import oracle_lib
+from slam_amd import capi, synthetic
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-9  # the tolerance the task states for log likelihoods and poses
+
+
+def small_problem(T=400, F=16, k=4, seed=3, range_stddev=2.0):
+    return synthetic.make_problem(T=T, n_landmarks=F, k_nearest=k, seed=seed, lap_steps=150, wobble_period=500,
+                                  range_stddev=range_stddev, landmark_spread=6.0)
+
+
+def oracle_world(p, seeds, trace=True, init_seed=None, steps_per_timestep=0, end_steps=0):
+    w = oracle_lib.World()
+    w.set_input(p["ctrl_mean"], p["ctrl_std"], p["obs_t"], p["obs_f"], p["obs_mean"], p["obs_std"])
+    if init_seed is not None:
+        w.set_initialiser(init_seed)
+    for s in seeds:
+        w.add_chain(int(s), steps_per_timestep=steps_per_timestep, end_steps=end_steps,
+                    use_initialiser=init_seed is not None, trace=trace)
+    return w
+
+
+def gpu_handle(p, seeds, trace_capacity, init_uniforms=None, **kw):
+    g = capi.McmcGpu(len(seeds), p["T"], p["F"], p["N"], trace_capacity=trace_capacity, **kw)
+    g.upload_problem(p["ctrl_mean"], p["ctrl_std"], p["obs_t"], p["obs_f"], p["obs_mean"], p["obs_std"], p["F"])
+    g.init_chains(seeds, init_uniforms)
+    return g
+
+
+def assert_close(a, b, rel, what, floor=1.0):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    scale = np.maximum(np.maximum(np.abs(a), np.abs(b)), floor)
+    err = np.abs(a - b) / scale
+    assert np.all(err <= rel), f"{what}: max rel err {err.max():.3e} at {np.argmax(err)}"
+
+
+def compare_traces(tg, to, ll_scale):
+    assert len(tg) == len(to), f"trace lengths differ: gpu {len(tg)} oracle {len(to)}"
+    assert np.array_equal(tg["kind"], to["kind"]), "edge kinds differ"
+    assert np.array_equal(tg["index"], to["index"]), "edge indices differ"
+    assert np.array_equal(tg["accepted"], to["accepted"]), "accept decisions differ"
+    assert_close(tg["proposed"], to["proposed"], 1e-11, "proposals")
+    # log ratios are differences of large sums: compare on the scale of the chain likelihood
+    assert_close(tg["log_ratio"], to["log_ratio"], REL, "log ratios", floor=ll_scale)
+    assert_close(tg["log_likelihood"], to["log_likelihood"], REL, "running log likelihood")
+
+
+def test_scan_affine_group_exact():
+    """The scan template on the reference tree test's non-commutative integer group."""
+    rng = np.random.default_rng(1)
+    P = 32749
+    for n in (1, 63, 64, 65, 255, 256, 257, 2000, 10000):
+        a = rng.integers(0, P, size=n).astype(np.int32)
+        b = rng.integers(1, P, size=n).astype(np.int32)
+        oa, ob = capi.selftest_scan(a, b, P)
+        ra, rb = np.empty(n, dtype=np.int64), np.empty(n, dtype=np.int64)
+        ca, cb = 0, 1
+        for i in range(n):
+            ca, cb = (ca + cb * int(a[i])) % P, (cb * int(b[i])) % P
+            ra[i], rb[i] = ca, cb
+        assert np.array_equal(oa, ra) and np.array_equal(ob, rb), f"n={n}"
+
+
+def test_seed_helpers_match_oracle():
+    assert np.array_equal(capi.seed_sequence(99, 50), oracle_lib.seed_sequence(99, 50))
+    assert np.array_equal(capi.uniform_sequence(7, 50), oracle_lib.uniform_sequence(7, 50))
+
+
+@pytest.mark.parametrize("uniform_first", [True, False])
+def test_grow_then_run_matches_oracle(uniform_first):
+    """multi_mcmc's way: chains grow over the whole data set without updates, then step."""
+    p = small_problem()
+    seeds = capi.seed_sequence(2024, 4)
+    steps = 600
+    w = oracle_lib.World()
+    w.set_input(p["ctrl_mean"], p["ctrl_std"], p["obs_t"], p["obs_f"], p["obs_mean"], p["obs_std"])
+    for s in seeds:
+        w.add_chain(int(s), uniform_first=uniform_first, trace=True)
+    w.replay(p["T"])
+    g = gpu_handle(p, seeds, trace_capacity=4096, feature_uniform_first=uniform_first)
+    g.grow(p["T"])
+    g.sync()
+    ll_grow = g.log_likelihood()
+    for c in range(len(seeds)):
+        assert_close(ll_grow[c], w.log_likelihood(c), REL, f"chain {c} log likelihood after growth")
+    for c in range(len(seeds)):
+        assert w.update(c, steps) >= 0
+    g.run(steps)
+    g.sync()
+    ll = g.log_likelihood()
+    full = g.full_log_likelihood()
+    upd, acc, units = g.counters()
+    for c in range(len(seeds)):
+        to, tg = w.trace(c), g.trace(c)
+        compare_traces(tg, to, abs(w.log_likelihood(c)))
+        assert_close(ll[c], w.log_likelihood(c), REL, f"chain {c} final log likelihood")
+        assert_close(full[c], w.full_log_likelihood(c), REL, f"chain {c} full log likelihood")
+        assert_close(ll[c], full[c], 1e-8, f"chain {c} incremental vs full")
+        so, sg = w.state(c), g.get_state(c)
+        assert np.array_equal(sg["feat_parent"], so["feat_parent"])
+        assert_close(sg["cum"], so["cum"], REL, "cumulative poses")
+        assert_close(sg["rel"], so["rel"], REL, "relative poses")
+        assert_close(sg["feat_est"], so["feat_est"], REL, "landmark estimates")
+        assert_close(sg["state_w"], so["state_w"], 1e-9, "state edge weights", floor=1e-300)
+        assert_close(sg["feat_w"], so["feat_w"], 1e-9, "landmark edge weights", floor=1e-300)
+        assert units[c] == w.units(c), "evaluated-observation counts differ"
+        assert upd[c] == steps
+
+
+def test_online_with_initialiser_matches_oracle():
+    """--mcmc-slam's way: initialiser, updates after every timestep, then end steps."""
+    p = small_problem(T=300, F=10, k=3, seed=11)
+    seeds = capi.seed_sequence(5, 6)  # module seeds, src/main.cpp:133-147
+    init_seed, chain_seed = int(seeds[1]), int(seeds[2])
+    w = oracle_world(p, [chain_seed], init_seed=init_seed, steps_per_timestep=5, end_steps=200)
+    w.replay(p["T"], finish=True)
+    g = gpu_handle(p, np.array([chain_seed], dtype=np.uint32), trace_capacity=4096,
+                   init_uniforms=capi.uniform_sequence(init_seed, p["F"]))
+    g.advance(p["T"], steps_per_timestep=5, end_steps=200)
+    g.sync()
+    compare_traces(g.trace(0), w.trace(0), abs(w.log_likelihood(0)))
+    assert_close(g.log_likelihood()[0], w.log_likelihood(0), REL, "final log likelihood")
+    assert_close(g.get_state(0)["cum"], w.state(0)["cum"], REL, "cumulative poses")
+
+
+def test_online_in_pieces_equals_one_call():
+    """Growing timestep by timestep with re-uploads of the growing problem gives the same chain."""
+    p = small_problem(T=120, F=8, k=3, seed=5)
+    seeds = np.array([77], dtype=np.uint32)
+    g1 = gpu_handle(p, seeds, trace_capacity=2048)
+    g1.advance(p["T"], steps_per_timestep=3, end_steps=50)
+    g1.sync()
+    g2 = capi.McmcGpu(1, p["T"], p["F"], p["N"], trace_capacity=2048)
+    g2.upload_problem(p["ctrl_mean"][:0], p["ctrl_std"][:0], p["obs_t"][:0], p["obs_f"][:0], p["obs_mean"][:0],
+                      p["obs_std"][:0], 0)
+    g2.init_chains(seeds)
+    for t in range(0, p["T"] + 1):
+        n = int(np.searchsorted(p["obs_t"], t, side="right"))
+        F = int(p["obs_f"][:n].max()) + 1 if n else 0
+        g2.upload_problem(p["ctrl_mean"][:t], p["ctrl_std"][:t], p["obs_t"][:n], p["obs_f"][:n], p["obs_mean"][:n],
+                          p["obs_std"][:n], F)
+        g2.advance(t, steps_per_timestep=3, end_steps=50 if t == p["T"] else 0)
+    g2.sync()
+    t1, t2 = g1.trace(0), g2.trace(0)
+    assert len(t1) == len(t2)
+    for name in ("kind", "index", "accepted", "log_ratio", "log_likelihood"):
+        assert np.array_equal(t1[name], t2[name]), name
+
+
+def test_eval_and_commit_entry_points():
+    """edge_log_likelihood_ratio for recorded proposals, and the accept branch applied from outside."""
+    p = small_problem(T=250, F=10, k=4, seed=21)
+    seeds = np.array([4242], dtype=np.uint32)
+    w = oracle_world(p, seeds)
+    w.replay(p["T"])
+    g = gpu_handle(p, seeds, trace_capacity=0)
+    g.grow(p["T"])
+    rng = np.random.default_rng(0)
+    so = w.state(0)
+    for it in range(60):
+        if it % 3 == 2:
+            f = int(rng.integers(0, p["F"]))
+            q = so["feat_est"][f] + rng.normal(0, 0.5, 2)
+            a, b = g.eval_llr(0, capi.FEATURE_EDGE, f, q), w.eval(0, 1, f, q)
+        else:
+            t = int(rng.integers(0, p["T"]))
+            q = so["rel"][t] + rng.normal(0, [0.02, 0.02, 0.005])
+            a, b = g.eval_llr(0, capi.STATE_EDGE, t, q), w.eval(0, 0, t, q)
+        assert_close(a, b, REL, f"log ratio #{it}", floor=abs(w.log_likelihood(0)))
+    # commit a state edge and a landmark edge by hand; the incremental likelihood must track the full one
+    t, q = 100, so["rel"][100] + np.array([0.01, -0.02, 0.003])
+    llr = g.eval_llr(0, capi.STATE_EDGE, t, q)
+    g.commit(0, capi.STATE_EDGE, t, q, 1.25, llr)
+    f, qf = 3, so["feat_est"][3] + np.array([0.3, -0.2])
+    llr = g.eval_llr(0, capi.FEATURE_EDGE, f, qf)
+    g.commit(0, capi.FEATURE_EDGE, f, qf, 0.75, llr)
+    g.sync()
+    st = g.get_state(0)
+    assert np.allclose(st["rel"][t], q, rtol=0, atol=0)
+    assert np.allclose(st["feat_est"][f], qf, rtol=0, atol=0)
+    assert_close(st["state_w"][t], 1.25, 1e-12, "committed state weight")
+    assert_close(st["feat_w"][f], 0.75, 1e-12, "committed landmark weight")
+    assert_close(g.log_likelihood()[0], g.full_log_likelihood()[0], 1e-9, "incremental vs full after commits")
+    # cumulative poses after the commit equal a from-scratch rebuild
+    before = st["cum"].copy()
+    g.rebuild()
+    assert_close(g.get_state(0)["cum"], before, 1e-11, "cumulative poses vs rebuild")
+
+
+def test_rebuild_scan_matches_oracle_accumulate():
+    p = small_problem(T=700, F=12, k=3, seed=8)
+    seeds = np.array([1], dtype=np.uint32)
+    w = oracle_world(p, seeds, trace=False)
+    w.replay(p["T"])
+    for shift in (6, 8):
+        g = gpu_handle(p, seeds, trace_capacity=0, block_shift=shift)
+        g.grow(p["T"])
+        g.rebuild()
+        assert_close(g.get_state(0)["cum"], w.state(0)["cum"], REL, f"scan, block shift {shift}")
+
+
+@pytest.mark.parametrize("threads", [64, 1024])
+def test_other_workgroup_sizes(threads):
+    p = small_problem(T=200, F=9, k=3, seed=13)
+    seeds = capi.seed_sequence(1, 2)
+    w = oracle_world(p, seeds)
+    w.replay(p["T"])
+    g = gpu_handle(p, seeds, trace_capacity=1024, threads_per_chain=threads)
+    g.grow(p["T"])
+    g.run(300)
+    g.sync()
+    for c in range(2):
+        w.update(c, 300)
+        compare_traces(g.trace(c), w.trace(c), abs(w.log_likelihood(c)))
+
+
+def test_plaza2_single_chain(plaza_dir):
+    """Plaza2, one chain on the GPU, --mcmc-slam --mcmc-steps 10 --mcmc-end-steps 1000 --sensor-range-stddev 1."""
+    w = oracle_lib.World()
+    w.load_plaza(plaza_dir, "Plaza2", 1.0)
+    inp = w.get_input()
+    obs_f, order = oracle_lib.dense_features(inp["obs_id"])
+    T, N = w.dims()
+    seeds = capi.seed_sequence(42, 6)
+    init_seed, chain_seed = int(seeds[1]), int(seeds[2])
+    w.set_initialiser(init_seed)
+    w.add_chain(chain_seed, steps_per_timestep=10, end_steps=1000, use_initialiser=True, trace=True)
+    w.replay(T, finish=True)
+    g = capi.McmcGpu(1, T, len(order), N, trace_capacity=T * 10 + 1000 + 4 * N)
+    g.upload_problem(inp["ctrl_mean"], inp["ctrl_std"], inp["obs_t"], obs_f, inp["obs_mean"], inp["obs_std"],
+                     len(order))
+    g.init_chains(np.array([chain_seed], dtype=np.uint32), capi.uniform_sequence(init_seed, len(order)))
+    g.advance(T, steps_per_timestep=10, end_steps=1000)
+    g.sync()
+    compare_traces(g.trace(0), w.trace(0), abs(w.log_likelihood(0)))
+    assert_close(g.log_likelihood()[0], w.log_likelihood(0), REL, "Plaza2 final log likelihood")
+    assert_close(g.full_log_likelihood()[0], w.full_log_likelihood(0), REL, "Plaza2 full log likelihood")
+    assert_close(g.get_state(0)["cum"], w.state(0)["cum"], REL, "Plaza2 cumulative poses")
