@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""Benchmark of the MCMC-SLAM proposal-evaluation path on MI355X.
+
+Metric (BASELINE.json): evaluated MCMC proposals*observations per second -- one
+unit is one execution of the reference's inner loop body
+(src/slam/mcmc_slam.hpp:487-502), i.e. one range reading evaluated for one
+proposal of one chain -- summed over all chains of all GPUs of the node.
+
+Workload (BASELINE.json configs[2], per GPU): synthetic planar robot, 100k poses,
+1k landmarks, 1M range readings, 1024 independent chains.  A bench "step" is one
+launch of the on-device Metropolis-Hastings loop doing `--updates-per-step`
+updates (mcmc_slam::update) on every chain, followed by the periodic exchange
+of per-chain summaries (all-gather over RCCL when N > 1) and the best-chain
+arg-max.  N GPUs run N x 1024 chains (weak scaling), one process per GPU.
+
+Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 under
+python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+BYTES_PER_UNIT = 32  # pose translation 16 B + range 8 B + timestep 4 B + landmark id 4 B
+BYTES_PER_LANDMARK = 20  # estimate 16 B + parent 4 B, read once per state-edge proposal
+BYTES_PER_MOVED_POSE = 48  # read + write of one 24 B cumulative pose on an accepted state edge
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--chains", type=int, default=1024, help="chains per GPU")
+    ap.add_argument("--updates-per-step", type=int, default=8)
+    ap.add_argument("--timesteps", type=int, default=100_000)
+    ap.add_argument("--landmarks", type=int, default=1000)
+    ap.add_argument("--k-nearest", type=int, default=10)
+    ap.add_argument("--seed", type=int, default=12345)
+    ap.add_argument("--rebuild-every", type=int, default=10, help="steps between cumulative-pose rebuilds")
+    ap.add_argument("--threads-per-chain", type=int, default=0)
+    ap.add_argument("--block-shift", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-plaza", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(problem, seed, target_seconds):
+    """The CPU oracle (restated reference algorithm, one thread, one chain) on a bounded
+    sample of the same workload: same problem, same starting state, same chain seed."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+
+    w = oracle_lib.World()
+    w.set_input(problem["ctrl_mean"], problem["ctrl_std"], problem["obs_t"], problem["obs_f"], problem["obs_mean"],
+                problem["obs_std"])
+    w.replay(problem["T"])
+    c = w.add_detached_chain(int(seed))
+    w.load_state(c, problem["true_rel"], np.arange(problem["F"]), problem["landmarks"])
+    probe = 8
+    t0 = time.perf_counter()
+    w.update(c, probe)
+    dt = max(time.perf_counter() - t0, 1e-6)
+    n = int(max(8, min(5000, target_seconds / (dt / probe))))
+    u0 = w.units(c)
+    t0 = time.perf_counter()
+    w.update(c, n)
+    dt = time.perf_counter() - t0
+    units = w.units(c) - u0
+    return {
+        "value": units / dt,
+        "unit": "proposals*observations/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"1 chain x {n} updates ({units} units, {dt:.1f} s) from the GPU run's starting state",
+    }
+
+
+def plaza1_wall(device, with_cpu):
+    """Plaza1 --mcmc-slam --mcmc-steps 10 --mcmc-end-steps 1000 --sensor-range-stddev 1: wall time of the
+    whole online replay, one chain on the GPU (and the CPU oracle beside it)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    from slam_amd import capi
+
+    plaza = os.path.join(ROOT, "tests", "golden", "plaza")
+    w = oracle_lib.World()  # used here as the data loader and, optionally, the CPU timing
+    w.load_plaza(plaza, "Plaza1", 1.0)
+    inp = w.get_input()
+    obs_f, order = oracle_lib.dense_features(inp["obs_id"])
+    T, N = w.dims()
+    seeds = capi.seed_sequence(42, 6)
+    out = {}
+    g = capi.McmcGpu(1, T, len(order), N, device=device)
+    t0 = time.perf_counter()
+    g.upload_problem(inp["ctrl_mean"], inp["ctrl_std"], inp["obs_t"], obs_f, inp["obs_mean"], inp["obs_std"],
+                     len(order))
+    g.init_chains(np.array([seeds[2]], dtype=np.uint32), capi.uniform_sequence(int(seeds[1]), len(order)))
+    g.advance(T, steps_per_timestep=10, end_steps=1000)
+    g.sync()
+    out["gpu_wall_s"] = time.perf_counter() - t0
+    out["gpu_log_likelihood"] = float(g.log_likelihood()[0])
+    g.close()
+    if with_cpu:
+        w.set_initialiser(int(seeds[1]))
+        w.add_chain(int(seeds[2]), steps_per_timestep=10, end_steps=1000, use_initialiser=True)
+        t0 = time.perf_counter()
+        w.replay(T, finish=True)
+        out["cpu_wall_s"] = time.perf_counter() - t0
+        out["cpu_log_likelihood"] = w.log_likelihood(0)
+    return out
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+
+    from slam_amd import capi, synthetic
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    problem = synthetic.make_problem(T=args.timesteps, n_landmarks=args.landmarks, k_nearest=args.k_nearest,
+                                     seed=args.seed)
+    T, F, N, C = problem["T"], problem["F"], problem["N"], args.chains
+    stream = torch.cuda.current_stream(dev)
+    g = capi.McmcGpu(C, T, F, N, device=local_rank, block_shift=args.block_shift,
+                     threads_per_chain=args.threads_per_chain, stream=stream.cuda_stream)
+    g.upload_problem(problem["ctrl_mean"], problem["ctrl_std"], problem["obs_t"], problem["obs_f"],
+                     problem["obs_mean"], problem["obs_std"], F)
+    # chain seeds the way multi_mcmc draws them (successive engine outputs), global chain numbering
+    all_seeds = capi.seed_sequence(args.seed + 2, C * world)
+    g.init_chains(all_seeds[rank * C:(rank + 1) * C])
+    g.load_state(problem["true_rel"], problem["landmarks"])
+    g.sync()
+
+    summaries = torch.zeros((C, 2), dtype=torch.float64, device=dev)  # mcmcgpu_chain_summary records
+    gathered = torch.zeros((C * world, 2), dtype=torch.float64, device=dev)
+    best = {"ll": float("-inf"), "chain": -1}
+
+    def one_step(i):
+        g.run(args.updates_per_step)
+        if args.rebuild_every and (i + 1) % args.rebuild_every == 0:
+            g.rebuild()
+        g.write_summaries(summaries.data_ptr())
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, summaries)
+            lls = gathered[:, 0]
+        else:
+            lls = summaries[:, 0]
+        ll, idx = torch.max(lls, dim=0)  # first maximum = lowest global chain id on ties
+        return ll, idx
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        one_step(i)
+    barrier()
+    g.kernel_time()  # reset the library's kernel timer
+    u0 = g.counters()
+    s0 = g.traffic_counters()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ll, idx = one_step(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    best["ll"], best["chain"] = float(ll), int(idx)
+    kern_ms, launches = g.kernel_time()
+    u1 = g.counters()
+    s1 = g.traffic_counters()
+    d_updates = int((u1[0] - u0[0]).sum())
+    d_accepts = int((u1[1] - u0[1]).sum())
+    d_units = int((u1[2] - u0[2]).sum())
+    d_state = int((s1[0] - s0[0]).sum())
+    d_moved = int((s1[1] - s0[1]).sum())
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    tot = torch.tensor([d_units, d_updates, d_accepts], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    elapsed_max = float(t.item())
+    units_total, updates_total, accepts_total = (float(x) for x in tot.tolist())
+
+    if rank == 0:
+        bytes_per_launch = (d_units * BYTES_PER_UNIT + d_state * F * BYTES_PER_LANDMARK +
+                            d_moved * BYTES_PER_MOVED_POSE) / max(launches, 1)
+        achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        out = {
+            "metric": "MCMC proposals*observations/sec (node) on 100k-pose synthetic",
+            "value": units_total / elapsed_max,
+            "unit": "proposals*observations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed_max / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "synthetic planar robot: %d poses, %d landmarks, %d range readings, %d chains per GPU" %
+                            (T, F, N, C),
+                "chains_total": C * world,
+                "updates_per_step": args.updates_per_step,
+                "parallelism": "chains sharded %dx%d, summaries all-gathered every step" % (world, C),
+                "start_state": "generating trajectory and landmark positions (mcmcgpu_load_state)",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel": "advance_kernel",
+                "kernel_ms": kern_ms,
+                "launches": launches,
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+            },
+            "proposals_per_s": updates_total / elapsed_max,
+            "accept_rate": accepts_total / max(updates_total, 1.0),
+            "units_per_proposal": units_total / max(updates_total, 1.0),
+            "best_log_likelihood": best["ll"],
+            "best_chain": best["chain"],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(problem, all_seeds[0], args.cpu_seconds)
+        if world == 1 and not args.no_plaza:
+            g.close()
+            out["plaza1"] = plaza1_wall(local_rank, with_cpu=not args.no_cpu_baseline)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

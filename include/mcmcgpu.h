@@ -149,6 +149,11 @@ int mcmcgpu_get_dims(mcmcgpu_handle h, uint32_t* timesteps, uint32_t* features, 
  * (executions of the loop body mcmc_slam.hpp:487-502), per chain. */
 int mcmcgpu_get_counters(mcmcgpu_handle h, uint64_t* updates, uint64_t* accepts, uint64_t* units);
 
+/* Counters for traffic accounting, per chain since init: state-edge proposals
+ * evaluated (each reads the landmark table once) and cumulative-pose entries
+ * rewritten by accepted state edges (block-local poses + block offsets). */
+int mcmcgpu_get_traffic_counters(mcmcgpu_handle h, uint64_t* state_proposals, uint64_t* moved_poses);
+
 /* Recorded steps of one chain (trace_capacity > 0); *count = number returned. */
 int mcmcgpu_get_trace(mcmcgpu_handle h, uint32_t chain, mcmcgpu_step_record* out, uint32_t capacity,
                       uint32_t* count);
@@ -161,6 +166,18 @@ int mcmcgpu_write_summaries(mcmcgpu_handle h, void* dev_out);
  * mcmcgpu_import_state is the receiving side. */
 int mcmcgpu_export_state(mcmcgpu_handle h, uint32_t chain, void* dev_out);
 int mcmcgpu_import_state(mcmcgpu_handle h, uint32_t chain, const void* dev_in, double log_likelihood);
+
+/* Puts chains [first, first+count) into one given state with the WHOLE uploaded
+ * problem already seen (restoring a checkpoint; also how a run is started from
+ * a known estimate, e.g. another back end's result as g2o_slam::reinitialise
+ * does for g2o, src/slam/g2o_slam.hpp:270-286): relative poses rel_poses[T][3]
+ * and world landmark positions feat_world[F][2].  Parents follow the rule of
+ * mcmc_slam::timestep (mcmc_slam.hpp:310-318: the reading with the smallest
+ * |range|, earliest on ties); edge weights (:240-241, 262-263), cumulative
+ * poses and the log likelihood (slam_likelihood.hpp:26-58) are derived on the
+ * device.  The chains' generators stay as mcmcgpu_init_chains seeded them. */
+int mcmcgpu_load_state(mcmcgpu_handle h, uint32_t first, uint32_t count, const double* rel_poses,
+                       const double* feat_world);
 
 /* Blocks until all work queued on the handle's stream is done and reports a
  * device-side error flag if any chain set one. */

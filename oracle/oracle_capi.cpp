@@ -313,6 +313,35 @@ void ora_chain_get_rng(void* p, int chain, std::uint32_t* mt, std::int32_t* idx,
   *saved = r.saved_value();
 }
 
+// Test-infrastructure extension (no reference counterpart): see mcmc_slam::load_state.
+// rel: [T][3]; world: [F][2] for landmark ids feat_id[F].
+int ora_chain_load_state(void* p, int chain, std::uint32_t T, const double* rel, std::uint32_t F,
+                         const std::uint32_t* feat_id, const double* world) {
+  struct world& w = *static_cast<struct world*>(p);
+  if (w.data.current_timestep() != T) return -1;
+  std::vector<pose> r(T);
+  for (std::uint32_t t = 0; t < T; ++t) r[t] = pose::cartesian(rel[3 * t], rel[3 * t + 1], rel[3 * t + 2]);
+  std::map<std::size_t, position> m;
+  for (std::uint32_t f = 0; f < F; ++f) m[feat_id[f]] = position::cartesian(world[2 * f], world[2 * f + 1]);
+  try {
+    w.chains[chain]->load_state(r, m);
+  } catch (const std::exception& e) {
+    w.error = e.what();
+    return -2;
+  }
+  return 0;
+}
+
+// Adds a chain that does NOT listen to the data (for load_state use).
+int ora_world_add_detached_chain(void* p, std::uint32_t seed, int uniform_first) {
+  struct world& w = *static_cast<struct world*>(p);
+  auto c = std::make_unique<mcmc_slam>(&w.data, seed);
+  c->uniform_first = uniform_first != 0;
+  w.chains.push_back(std::move(c));
+  w.traces.emplace_back();
+  return int(w.chains.size()) - 1;
+}
+
 double ora_chain_eval(void* p, int chain, int kind, std::uint32_t index, const double* proposed) {
   world& w = *static_cast<world*>(p);
   mcmc_slam& c = *w.chains[chain];

@@ -868,6 +868,16 @@ class mcmc_slam : public slam_data::listener, public slam_result {
     }
   }
 
+  // NOT IN THE REFERENCE (test infrastructure): puts the chain into a given
+  // state with all of `data` already seen -- relative poses rel[t], world
+  // landmark positions by id.  Every derived quantity follows the reference's
+  // own rules: a landmark's parent is the reading the growth loop would have
+  // ended with (:310-318, strictly smaller |range| wins, in time order); edge
+  // weights are edge_log_weight of the current value (:240-241, :262-263,
+  // :388-390); the likelihood is slam_log_likelihood.  The generator is left
+  // untouched.  Lets a CPU baseline start from the same point as a GPU run.
+  void load_state(const std::vector<pose>& rel, const std::map<std::size_t, position>& world);
+
   // Evaluate (without side effects on the chain) the log-likelihood ratio of a
   // given proposal -- the quantity :385 feeds into the accept test.
   double eval_state_edge(std::size_t t, const pose& proposed) { return state_edge_log_likelihood_ratio(t, proposed); }
@@ -911,6 +921,37 @@ inline double slam_log_likelihood(const slam_data& data, const slam_result& esti
     }
   }
   return ll;
+}
+
+inline void mcmc_slam::load_state(const std::vector<pose>& rel, const std::map<std::size_t, position>& world) {
+  state_estimates.clear();
+  state_weights.clear();
+  feature_estimates.clear();
+  feature_weights.clear();
+  feature_index.clear();
+  map_estimate.clear();
+  for (std::size_t t = 0; t < rel.size(); ++t) {
+    const velocity_slip_model& control = data->control(t);
+    state_estimates.push_back(rel[t]);
+    state_weights.push_back(
+        std::exp(edge_log_weight(control.proposal_log_likelihood(rel[t]), velocity_slip_model::proposal_dim)));
+  }
+  // landmarks in order of first appearance, as timestep() would have met them
+  for (const auto& ob : data->observations) {
+    const std::size_t id = ob.second.id;
+    if (!feature_index.emplace(id, feature_estimates.size()).second) continue;
+    const auto& list = data->get_observations(id);
+    std::size_t parent = 0;
+    for (std::size_t i = 1; i < list.size(); ++i)
+      if (list[i].second.more_accurate_than(list[parent].second)) parent = i;
+    const std::size_t pt = list[parent].first;
+    const position est = -get_state(pt) + world.at(id);
+    feature_estimates.push_back({id, pt, est});
+    feature_weights.push_back(std::exp(
+        edge_log_weight(list[parent].second.proposal_log_likelihood(est), range_only_model::proposal_dim)));
+  }
+  next_timestep = rel.size() + 1;
+  log_likelihood = slam_log_likelihood(*data, *this);
 }
 
 // src/slam/multi_mcmc.hpp:34-169

@@ -62,10 +62,12 @@ EXPORTS = [
     "mcmcgpu_get_state",
     "mcmcgpu_get_dims",
     "mcmcgpu_get_counters",
+    "mcmcgpu_get_traffic_counters",
     "mcmcgpu_get_trace",
     "mcmcgpu_write_summaries",
     "mcmcgpu_export_state",
     "mcmcgpu_import_state",
+    "mcmcgpu_load_state",
     "mcmcgpu_sync",
     "mcmcgpu_kernel_time",
     "mcmcgpu_seed_sequence",
@@ -241,6 +243,12 @@ class McmcGpu:
         self._check(self.lib.mcmcgpu_get_counters(self.h, _ptr(u), _ptr(a), _ptr(n)), "mcmcgpu_get_counters")
         return u, a, n
 
+    def traffic_counters(self):
+        s = np.empty(self.chains, dtype=np.uint64)
+        m = np.empty(self.chains, dtype=np.uint64)
+        self._check(self.lib.mcmcgpu_get_traffic_counters(self.h, _ptr(s), _ptr(m)), "mcmcgpu_get_traffic_counters")
+        return s, m
+
     def trace(self, chain):
         out = np.zeros(max(self.trace_capacity, 1), dtype=STEP_RECORD)
         n = ctypes.c_uint32()
@@ -260,6 +268,14 @@ class McmcGpu:
         self._check(
             self.lib.mcmcgpu_import_state(self.h, ctypes.c_uint32(chain), ctypes.c_void_p(dev_ptr),
                                           ctypes.c_double(log_likelihood)), "mcmcgpu_import_state")
+
+    def load_state(self, rel_poses, feat_world, first=0, count=None):
+        rel = np.ascontiguousarray(rel_poses, dtype=np.float64)
+        fw = np.ascontiguousarray(feat_world, dtype=np.float64)
+        count = self.chains - first if count is None else count
+        self._check(
+            self.lib.mcmcgpu_load_state(self.h, ctypes.c_uint32(first), ctypes.c_uint32(count), _ptr(rel), _ptr(fw)),
+            "mcmcgpu_load_state")
 
     def sync(self):
         self._check(self.lib.mcmcgpu_sync(self.h), "mcmcgpu_sync")

@@ -69,6 +69,7 @@ struct Dev {
   int32_t* nflag;               // [C]
   double* nsaved;               // [C]
   unsigned long long *n_updates, *n_accepts, *n_units;  // [C]
+  unsigned long long *n_state_props, *n_moved;          // [C] state-edge proposals; poses rewritten by commits
   uint32_t* errflag;            // [C]
   mcmcgpu_step_record* trace;   // [C][trace_cap] or null
   uint32_t trace_cap;
@@ -95,7 +96,7 @@ struct Shared {
   int pending, use_weight;
   double new_pll, old_pll;
   uint32_t rp_obs;
-  unsigned long long n_upd, n_acc, n_units;
+  unsigned long long n_upd, n_acc, n_units, n_state, n_moved;
   uint32_t failed;
   // request posted by the driver
   int op;
@@ -653,6 +654,8 @@ MG_DEV void chain_state_load(const Dev& d, uint32_t c, Shared& S) {
     S.n_upd = 0;
     S.n_acc = 0;
     S.n_units = 0;
+    S.n_state = 0;
+    S.n_moved = 0;
     S.failed = 0;
     S.pending = PEND_NONE;
   }
@@ -669,6 +672,8 @@ MG_DEV void chain_state_store(const Dev& d, uint32_t c, Shared& S) {
     d.n_updates[c] += S.n_upd;
     d.n_accepts[c] += S.n_acc;
     d.n_units[c] += S.n_units;
+    d.n_state_props[c] += S.n_state;
+    d.n_moved[c] += S.n_moved;
     if (S.failed) d.errflag[c] = 1;
   }
 }
@@ -705,6 +710,7 @@ __global__ void advance_kernel(Dev d, uint32_t first_tn, uint32_t Tcur0, uint32_
       r = eval_feature_edge(d, c, S, idx, Vec2{q.x, q.y}, units);
     if (threadIdx.x == 0) {
       S.n_units += units;
+      if (op == OP_EVAL_STATE) ++S.n_state;
       const bool accept = driver_finish_update(d, c, S, r);
       S.accept = accept ? 1 : 0;
       if (S.pending == PEND_UPDATE) {
@@ -726,6 +732,9 @@ __global__ void advance_kernel(Dev d, uint32_t first_tn, uint32_t Tcur0, uint32_
         d.relx[ri] = q.x;
         d.rely[ri] = q.y;
         d.relth[ri] = q.th;
+        // poses rewritten: the rest of pose idx+1's block plus the later block offsets
+        const uint32_t k1 = idx + 1, kend = ((k1 >> d.sh) << d.sh) + (1u << d.sh) - 1;
+        S.n_moved += ((kend < Tcur ? kend : Tcur) - k1 + 1) + ((Tcur >> d.sh) - (k1 >> d.sh));
       }
     }
     __syncthreads();
@@ -858,9 +867,9 @@ __global__ void readout_kernel(Dev d, uint32_t c, uint32_t Tcur, double* feat_wo
 }
 
 // slam_log_likelihood (src/slam/slam_likelihood.hpp:26-58); grid = chains.
-__global__ void full_ll_kernel(Dev d, uint32_t Tcur, double* out) {
+__global__ void full_ll_kernel(Dev d, uint32_t first, uint32_t Tcur, double* out) {
   __shared__ Shared S;
-  const uint32_t c = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  const uint32_t c = first + blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
   const uint32_t segcap = nthr < uint32_t(kMaxSeg) ? nthr : uint32_t(kMaxSeg);
   double acc = 0.0;
   for (uint32_t t = tid; t < Tcur; t += nthr) {
@@ -910,6 +919,8 @@ __global__ void init_chains_kernel(Dev d, const uint32_t* seeds) {
   d.n_updates[c] = 0;
   d.n_accepts[c] = 0;
   d.n_units[c] = 0;
+  d.n_state_props[c] = 0;
+  d.n_moved[c] = 0;
   d.errflag[c] = 0;
   if (d.trace_n) d.trace_n[c] = 0;
   d.locx[size_t(c) * (d.Tcap + 1)] = 0.0;
@@ -927,27 +938,71 @@ __global__ void summaries_kernel(Dev d, mcmcgpu_chain_summary* out) {
   out[c].accepts = uint32_t(d.n_accepts[c]);
 }
 
-// Recomputes both weight trees of one chain from its current estimates (each
-// edge weight is a function of the edge's current value: mcmc_slam.hpp:240-241,
-// 262-263, 388-390).  One lane; used after importing a foreign state.
-__global__ void reweigh_kernel(Dev d, uint32_t c, uint32_t Tcur) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// Recomputes both weight trees of chains [first, first + gridDim.x) from their
+// current estimates (each edge weight is a function of the edge's current
+// value: mcmc_slam.hpp:240-241, 262-263, 388-390).  A tree node only depends on
+// nodes whose lowest set index bit is smaller, so the tree is filled level by
+// level; inside a node the additions happen in the order push_back would use.
+MG_DEV void build_tree_levels(double* node, uint32_t n) {
+  for (uint32_t low = 2; low < n; low <<= 1) {
+    __syncthreads();
+    for (uint32_t i = low * (2 * threadIdx.x + 1); i < n; i += 2 * low * blockDim.x)
+      node[i] = wt::sum_to_ancestor(node, i - 1, wt::parent(i)) + node[i];
+  }
+  __syncthreads();
+}
+__global__ void reweigh_kernel(Dev d, uint32_t first, uint32_t Tcur) {
+  const uint32_t c = first + blockIdx.x;
   double* sw = d.sw + size_t(c) * d.Tcap;
-  for (uint32_t t = 0; t < Tcur; ++t) {
+  for (uint32_t t = threadIdx.x; t < Tcur; t += blockDim.x) {
     double mu[3], sd[3];
     load_control(d, t, mu, sd);
     const size_t ri = size_t(c) * d.Tcap + t;
     const double lp = control_log_pdf(mu, sd, Pose{d.relx[ri], d.rely[ri], d.relth[ri]});
-    wt::push_back(sw, t, edge_weight_from_log_pdf(lp, 3.0, nullptr));
+    sw[t] = edge_weight_from_log_pdf(lp, 3.0, nullptr);
   }
+  build_tree_levels(sw, Tcur);
   double* fw = d.fw + size_t(c) * d.Fcap;
   const uint32_t nf = d.nf[c];
-  for (uint32_t f = 0; f < nf; ++f) {
+  for (uint32_t f = threadIdx.x; f < nf; f += blockDim.x) {
     const size_t fi = size_t(c) * d.Fcap + f;
     const uint32_t po = d.foff[f] + d.fpar[fi];
     const double lp = range_proposal_log_pdf(d.omu[po], d.osd[po], Vec2{d.fex[fi], d.fey[fi]});
-    wt::push_back(fw, f, edge_weight_from_log_pdf(lp, 2.0, nullptr));
+    fw[f] = edge_weight_from_log_pdf(lp, 2.0, nullptr);
   }
+  build_tree_levels(fw, nf);
+}
+
+// Copies one staged state into chains [first, first + gridDim.x): relative
+// poses rel[T][3] and the per-landmark bookkeeping fmeta[4][F] (parent reading,
+// readings seen, parent timestep, last timestep).
+__global__ void load_state_kernel(Dev d, uint32_t first, uint32_t T, uint32_t F, const double* rel,
+                                  const uint32_t* fmeta) {
+  const uint32_t c = first + blockIdx.x;
+  const size_t rbase = size_t(c) * d.Tcap, fbase = size_t(c) * d.Fcap;
+  for (uint32_t t = threadIdx.x; t < T; t += blockDim.x) {
+    d.relx[rbase + t] = rel[3 * size_t(t)];
+    d.rely[rbase + t] = rel[3 * size_t(t) + 1];
+    d.relth[rbase + t] = rel[3 * size_t(t) + 2];
+  }
+  for (uint32_t f = threadIdx.x; f < F; f += blockDim.x) {
+    d.fpar[fbase + f] = fmeta[f];
+    d.fcnt[fbase + f] = fmeta[size_t(F) + f];
+    d.fpt[fbase + f] = fmeta[2 * size_t(F) + f];
+    d.flast[fbase + f] = fmeta[3 * size_t(F) + f];
+  }
+  if (threadIdx.x == 0) d.nf[c] = F;
+}
+
+// Landmark estimates relative to their parent poses from world positions;
+// grid = (ceil(F / block), chains).
+__global__ void features_from_world_kernel(Dev d, uint32_t first, uint32_t F, const double* world) {
+  const uint32_t c = first + blockIdx.y, f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  const size_t fi = size_t(c) * d.Fcap + f;
+  const Vec2 e = act_inverse(world_pose(d, c, d.fpt[fi]), Vec2{world[2 * size_t(f)], world[2 * size_t(f) + 1]});
+  d.fex[fi] = e.x;
+  d.fey[fi] = e.y;
 }
 
 // Scan self-test over the integer affine group (exact).

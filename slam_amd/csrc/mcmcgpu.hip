@@ -41,6 +41,8 @@ struct mcmcgpu_ctx {
   uint32_t chains = 0;
   bool problem_loaded = false;
   uint32_t next_timestep = 0;  // first timestep the chains have not processed
+  std::vector<uint32_t> h_foff, h_ot;  // host copies of the landmark-major index
+  std::vector<double> h_omu;
   std::vector<EventPair> timings;
   std::vector<EventPair> free_events;
   std::string error;
@@ -189,6 +191,8 @@ int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out) {
   ALLOC(d.n_updates, C);
   ALLOC(d.n_accepts, C);
   ALLOC(d.n_units, C);
+  ALLOC(d.n_state_props, C);
+  ALLOC(d.n_moved, C);
   ALLOC(d.errflag, C);
   ALLOC(d.trace_n, C);
   if (d.trace_cap) ALLOC(d.trace, C * d.trace_cap);
@@ -291,6 +295,9 @@ int mcmcgpu_upload_problem(mcmcgpu_handle h, uint32_t T, const double* ctrl_mean
   d.T = T;
   d.N = N;
   d.F = F;
+  h->h_foff = foff;
+  h->h_ot = ot;
+  h->h_omu = omu;
   h->problem_loaded = true;
   return 0;
 }
@@ -421,7 +428,7 @@ int mcmcgpu_full_log_likelihood(mcmcgpu_handle h, double* out) {
   double* dout = nullptr;
   // the per-chain results go to the tile-total buffer of the rebuild scan (idle here)
   dout = reinterpret_cast<double*>(h->scan_tot);
-  hipLaunchKernelGGL(full_ll_kernel, dim3(h->chains), dim3(h->nthreads), 0, h->stream, h->d, edges_grown(h), dout);
+  hipLaunchKernelGGL(full_ll_kernel, dim3(h->chains), dim3(h->nthreads), 0, h->stream, h->d, 0u, edges_grown(h), dout);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemcpyAsync(out, dout, sizeof(double) * h->chains, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -519,6 +526,17 @@ int mcmcgpu_get_counters(mcmcgpu_handle h, uint64_t* updates, uint64_t* accepts,
   return 0;
 }
 
+int mcmcgpu_get_traffic_counters(mcmcgpu_handle h, uint64_t* state_proposals, uint64_t* moved_poses) {
+  if (!h) return MCMCGPU_ERR_ARGUMENT;
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  const size_t bytes = sizeof(uint64_t) * h->chains;
+  if (state_proposals)
+    HIP_TRY(h, hipMemcpyAsync(state_proposals, h->d.n_state_props, bytes, hipMemcpyDeviceToHost, h->stream));
+  if (moved_poses) HIP_TRY(h, hipMemcpyAsync(moved_poses, h->d.n_moved, bytes, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
 int mcmcgpu_get_trace(mcmcgpu_handle h, uint32_t chain, mcmcgpu_step_record* out, uint32_t capacity,
                       uint32_t* count) {
   if (!h || !count) return fail(h, MCMCGPU_ERR_ARGUMENT, "null argument");
@@ -584,9 +602,58 @@ int mcmcgpu_import_state(mcmcgpu_handle h, uint32_t chain, const void* dev_in, d
   HIP_TRY(h, cp(d.fey + size_t(chain) * d.Fcap, in + 3 * T + F, F));
   HIP_TRY(h, hipMemcpyAsync(d.ll + chain, &log_likelihood, sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
-  hipLaunchKernelGGL(reweigh_kernel, dim3(1), dim3(64), 0, h->stream, d, chain, uint32_t(T));
+  HIP_TRY(h, rebuild_impl(h) == 0 ? hipSuccess : hipErrorUnknown);
+  hipLaunchKernelGGL(reweigh_kernel, dim3(1), dim3(256), 0, h->stream, d, chain, uint32_t(T));
   HIP_TRY(h, hipGetLastError());
-  return rebuild_impl(h);
+  return 0;
+}
+
+int mcmcgpu_load_state(mcmcgpu_handle h, uint32_t first, uint32_t count, const double* rel_poses,
+                       const double* feat_world) {
+  if (!h || !rel_poses || !feat_world) return fail(h, MCMCGPU_ERR_ARGUMENT, "null argument");
+  if (!h->problem_loaded || h->chains == 0) return fail(h, MCMCGPU_ERR_STATE, "upload a problem and init chains first");
+  if (count == 0 || first + count > h->chains) return fail(h, MCMCGPU_ERR_ARGUMENT, "chain range out of bounds");
+  Dev& d = h->d;
+  const uint32_t T = d.T, F = d.F;
+  if (h->next_timestep != T + 1 && !(first == 0 && count == h->chains))
+    return fail(h, MCMCGPU_ERR_STATE, "chains that have not seen the whole problem can only be loaded all together");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  // per-landmark bookkeeping for "every reading seen": the parent is the reading
+  // growth would end with (strictly smaller |range| wins, in time order)
+  std::vector<uint32_t> fmeta(4 * size_t(F));
+  for (uint32_t f = 0; f < F; ++f) {
+    const uint32_t lo = h->h_foff[f], hi = h->h_foff[f + 1];
+    uint32_t par = lo;
+    for (uint32_t o = lo + 1; o < hi; ++o)
+      if (std::fabs(h->h_omu[o]) < std::fabs(h->h_omu[par])) par = o;
+    fmeta[f] = par - lo;
+    fmeta[size_t(F) + f] = hi - lo;
+    fmeta[2 * size_t(F) + f] = h->h_ot[par];
+    fmeta[3 * size_t(F) + f] = h->h_ot[hi - 1];
+  }
+  double* drel = h->scratch;                                      // [T][3]
+  double* dworld = drel + 3 * size_t(T);                          // [F][2]
+  uint32_t* dmeta = reinterpret_cast<uint32_t*>(dworld + 2 * size_t(F));  // [4][F]
+  auto up = [&](void* dst, const void* src, size_t bytes) {
+    return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream) : hipSuccess;
+  };
+  HIP_TRY(h, up(drel, rel_poses, sizeof(double) * 3 * T));
+  HIP_TRY(h, up(dworld, feat_world, sizeof(double) * 2 * F));
+  HIP_TRY(h, up(dmeta, fmeta.data(), sizeof(uint32_t) * fmeta.size()));
+  hipLaunchKernelGGL(load_state_kernel, dim3(count), dim3(256), 0, h->stream, d, first, T, F, drel, dmeta);
+  HIP_TRY(h, hipGetLastError());
+  h->next_timestep = T + 1;
+  if (int rc = rebuild_impl(h)) return rc;
+  if (F) {
+    hipLaunchKernelGGL(features_from_world_kernel, dim3((F + 255) / 256, count), dim3(256), 0, h->stream, d, first, F,
+                       dworld);
+    HIP_TRY(h, hipGetLastError());
+  }
+  hipLaunchKernelGGL(reweigh_kernel, dim3(count), dim3(256), 0, h->stream, d, first, T);
+  hipLaunchKernelGGL(full_ll_kernel, dim3(count), dim3(h->nthreads), 0, h->stream, d, first, T, d.ll);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipStreamSynchronize(h->stream));  // host staging vector dies here
+  return 0;
 }
 
 int mcmcgpu_sync(mcmcgpu_handle h) {

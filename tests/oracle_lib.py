@@ -117,6 +117,23 @@ class World:
         self.nchains = c + 1
         return c
 
+    def add_detached_chain(self, seed, uniform_first=True, trace=False):
+        """A chain that does not listen to the data; bring it to life with load_state()."""
+        c = self.L.ora_world_add_detached_chain(self.w, ctypes.c_uint32(seed), int(uniform_first))
+        if trace:
+            self.L.ora_chain_trace_enable(self.w, c)
+        self.nchains = c + 1
+        return c
+
+    def load_state(self, chain, rel, feat_id, feat_world):
+        rel = np.ascontiguousarray(rel, dtype=np.float64)
+        fid = np.ascontiguousarray(feat_id, dtype=np.uint32)
+        fw = np.ascontiguousarray(feat_world, dtype=np.float64)
+        rc = self.L.ora_chain_load_state(self.w, chain, ctypes.c_uint32(rel.shape[0]), _p(rel), ctypes.c_uint32(fid.size),
+                                         _p(fid), _p(fw))
+        if rc != 0:
+            raise RuntimeError(f"ora_chain_load_state failed ({rc}): {self.L.ora_world_error(self.w).decode()}")
+
     def replay(self, upto, finish=False):
         rc = self.L.ora_world_replay(self.w, ctypes.c_uint32(upto), int(finish))
         if rc != 0:

@@ -244,3 +244,41 @@ def test_plaza2_single_chain(plaza_dir):
     assert_close(g.log_likelihood()[0], w.log_likelihood(0), REL, "Plaza2 final log likelihood")
     assert_close(g.full_log_likelihood()[0], w.full_log_likelihood(0), REL, "Plaza2 full log likelihood")
     assert_close(g.get_state(0)["cum"], w.state(0)["cum"], REL, "Plaza2 cumulative poses")
+
+
+def test_load_state_then_run_matches_oracle():
+    """Chains started from a given state (the benchmark's way) step exactly like the oracle's."""
+    p = synthetic.make_problem(T=3000, n_landmarks=60, k_nearest=5, seed=17, lap_steps=400, wobble_period=900,
+                               range_stddev=1.0, landmark_spread=8.0)
+    seeds = capi.seed_sequence(31, 3)
+    steps = 400
+    w = oracle_lib.World()
+    w.set_input(p["ctrl_mean"], p["ctrl_std"], p["obs_t"], p["obs_f"], p["obs_mean"], p["obs_std"])
+    w.replay(p["T"])
+    for s in seeds:
+        c = w.add_detached_chain(int(s), trace=True)
+        w.load_state(c, p["true_rel"], np.arange(p["F"]), p["landmarks"])
+    g = gpu_handle(p, seeds, trace_capacity=steps)
+    g.load_state(p["true_rel"], p["landmarks"])
+    ll0 = g.log_likelihood()
+    for c in range(len(seeds)):
+        assert_close(ll0[c], w.log_likelihood(c), REL, "log likelihood of the loaded state")
+        so, sg = w.state(c), g.get_state(c)
+        assert np.array_equal(sg["feat_parent"], so["feat_parent"])
+        assert_close(sg["cum"], so["cum"], REL, "cumulative poses of the loaded state")
+        assert_close(sg["feat_est"], so["feat_est"], REL, "landmark estimates of the loaded state")
+        assert_close(sg["state_w"], so["state_w"], 1e-9, "state weights", floor=1e-300)
+        assert_close(sg["feat_w"], so["feat_w"], 1e-9, "landmark weights", floor=1e-300)
+    g.run(steps)
+    g.sync()
+    ll = g.log_likelihood()
+    _, _, units = g.counters()
+    for c in range(len(seeds)):
+        assert w.update(c, steps) >= 0
+        compare_traces(g.trace(c), w.trace(c), abs(w.log_likelihood(c)))
+        assert_close(ll[c], w.log_likelihood(c), REL, "final log likelihood")
+        assert units[c] == w.units(c)
+    # drift control: a rebuild changes nothing beyond rounding
+    before = g.get_state(0)["cum"].copy()
+    g.rebuild()
+    assert_close(g.get_state(0)["cum"], before, 1e-11, "rebuild after many commits")
