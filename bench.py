@@ -46,7 +46,6 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--rebuild-every", type=int, default=10, help="steps between cumulative-pose rebuilds")
     ap.add_argument("--threads-per-chain", type=int, default=0)
-    ap.add_argument("--block-shift", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-plaza", action="store_true")
@@ -140,7 +139,7 @@ def main():
                                      seed=args.seed)
     T, F, N, C = problem["T"], problem["F"], problem["N"], args.chains
     stream = torch.cuda.current_stream(dev)
-    g = capi.McmcGpu(C, T, F, N, device=local_rank, block_shift=args.block_shift,
+    g = capi.McmcGpu(C, T, F, N, device=local_rank,
                      threads_per_chain=args.threads_per_chain, stream=stream.cuda_stream)
     g.upload_problem(problem["ctrl_mean"], problem["ctrl_std"], problem["obs_t"], problem["obs_f"],
                      problem["obs_mean"], problem["obs_std"], F)

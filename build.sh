@@ -5,4 +5,7 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 $HIPCC -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared -std=c++17 \
   -Wall -Wno-unused-function -o slam_amd/libmcmcgpu.so slam_amd/csrc/mcmcgpu.hip
+# diagnostic twin with per-phase cycle stamps (never used for reported numbers)
+$HIPCC -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared -std=c++17 -DMG_PHASE_TIMING \
+  -Wall -Wno-unused-function -o slam_amd/libmcmcgpu_diag.so slam_amd/csrc/mcmcgpu.hip
 make -s -C oracle

@@ -43,7 +43,6 @@ typedef struct mcmcgpu_config {
   uint32_t max_timesteps;     /* capacity for controls (state edges) */
   uint32_t max_features;      /* capacity for landmarks */
   uint32_t max_observations;  /* capacity for range readings */
-  uint32_t block_shift;       /* log2 of poses per cumulative-pose block; 0 -> 8 */
   uint32_t threads_per_chain; /* workgroup size; 0 -> 256; multiple of 64, <= 1024 */
   /* Order of the two draws inside a landmark proposal.  The reference leaves it
    * unsequenced (src/planar_robot/range_bearing_model.hpp:155-159): 1 = uniform
@@ -193,6 +192,13 @@ int mcmcgpu_kernel_time(mcmcgpu_handle h, double* avg_ms, uint32_t* launches);
  * per new landmark, src/slam/slam_initialiser.hpp:44-47). */
 void mcmcgpu_seed_sequence(uint32_t seed, uint32_t n, uint32_t* out);
 void mcmcgpu_uniform_sequence(uint32_t seed, uint32_t n, double* out);
+
+/* Diagnostic builds only (-DMG_PHASE_TIMING): shader-clock cycles lane 0 of every
+ * chain spent per phase of the advance kernel, summed over chains -- [0] serial
+ * selection/proposal, [1] state edge: landmark set-up, [2] state edge: reading
+ * stream, [3] landmark edge evaluation, [4] reduction + accept test, [5] commit,
+ * [6] whole kernel.  A normal build returns MCMCGPU_ERR_STATE. */
+int mcmcgpu_debug_phase_cycles(mcmcgpu_handle h, uint64_t out[8], int reset);
 
 /* Test hook for the scan building block: inclusive prefix "sums" of n affine
  * maps x -> a + b*x (mod p) under composition, computed by the same wavefront

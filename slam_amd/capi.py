@@ -8,7 +8,7 @@ import os
 
 import numpy as np
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmcmcgpu.so")
+_LIB_PATH = os.environ.get("MCMCGPU_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmcmcgpu.so")
 
 STATE_EDGE = 0
 FEATURE_EDGE = 1
@@ -21,7 +21,6 @@ class Config(ctypes.Structure):
         ("max_timesteps", ctypes.c_uint32),
         ("max_features", ctypes.c_uint32),
         ("max_observations", ctypes.c_uint32),
-        ("block_shift", ctypes.c_uint32),
         ("threads_per_chain", ctypes.c_uint32),
         ("feature_uniform_first", ctypes.c_uint32),
         ("trace_capacity", ctypes.c_uint32),
@@ -72,6 +71,7 @@ EXPORTS = [
     "mcmcgpu_kernel_time",
     "mcmcgpu_seed_sequence",
     "mcmcgpu_uniform_sequence",
+    "mcmcgpu_debug_phase_cycles",
     "mcmcgpu_selftest_scan",
 ]
 
@@ -126,10 +126,10 @@ def selftest_scan(a, b, p, device=0):
 class McmcGpu:
     """One handle = C chains on one GPU."""
 
-    def __init__(self, max_chains, max_timesteps, max_features, max_observations, device=0, block_shift=0,
+    def __init__(self, max_chains, max_timesteps, max_features, max_observations, device=0,
                  threads_per_chain=0, feature_uniform_first=True, trace_capacity=0, stream=None):
         self.lib = load_library()
-        cfg = Config(device, max_chains, max_timesteps, max_features, max_observations, block_shift, threads_per_chain,
+        cfg = Config(device, max_chains, max_timesteps, max_features, max_observations, threads_per_chain,
                      1 if feature_uniform_first else 0, trace_capacity, stream)
         self.h = ctypes.c_void_p()
         rc = self.lib.mcmcgpu_create(ctypes.byref(cfg), ctypes.byref(self.h))
@@ -276,6 +276,12 @@ class McmcGpu:
         self._check(
             self.lib.mcmcgpu_load_state(self.h, ctypes.c_uint32(first), ctypes.c_uint32(count), _ptr(rel), _ptr(fw)),
             "mcmcgpu_load_state")
+
+    def debug_phase_cycles(self, reset=True):
+        out = np.zeros(8, dtype=np.uint64)
+        self._check(self.lib.mcmcgpu_debug_phase_cycles(self.h, _ptr(out), ctypes.c_int(1 if reset else 0)),
+                    "mcmcgpu_debug_phase_cycles")
+        return out
 
     def sync(self):
         self._check(self.lib.mcmcgpu_sync(self.h), "mcmcgpu_sync")

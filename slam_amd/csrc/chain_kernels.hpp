@@ -9,17 +9,18 @@
 // growth :227-336) and posts requests; all lanes then serve the data-parallel
 // parts together:
 //   * eval_state_edge / eval_feature_edge -- the fused observation
-//     log-likelihood-ratio reduction (mcmc_slam.hpp:432-505), HBM/L2 bound;
+//     log-likelihood-ratio reduction (mcmc_slam.hpp:432-505);
 //   * commit_state_edge -- the rigid re-positioning of the cumulative poses
 //     behind an accepted state edge.
 //
-// Cumulative poses (what the reference keeps in bitree<pose>) are stored in two
-// levels, struct-of-arrays: P[k] = block_offset[k >> sh] o local[k], local[]
-// being the prefix composition inside a block of 2^sh poses.  Any P[k] is O(1)
-// to read, and an accepted proposal at edge t touches at most 2^sh local poses
-// plus T/2^sh block offsets instead of every pose after t.  A range reading
-// only needs the TRANSLATION of P[s]: |P[s]^-1 w| = |w - t_s| for a world point
-// w, so the hot loop reads 16 B of pose per reading and no angle.
+// Cumulative poses (what the reference keeps in bitree<pose>) are a flat
+// per-chain table P[k] in world coordinates: translation as one 16-byte record
+// (so a reading costs ONE 16-byte gather) and the unwrapped angle beside it.
+// The table is built by the SE(2) prefix scan in scan.hpp and kept current by
+// commit_state_edge, which rewrites the poses after an accepted edge (a point
+// update followed by re-evaluation of the affected prefix sums).  A range
+// reading only needs the TRANSLATION of P[s]: |P[s]^-1 w| = |w - t_s| for a
+// world point w, so the hot loop never touches an angle.
 #ifndef SLAM_AMD_CHAIN_KERNELS_HPP
 #define SLAM_AMD_CHAIN_KERNELS_HPP
 
@@ -29,8 +30,15 @@
 
 namespace mg {
 
-struct alignas(32) BlockXf {
-  double x, y, c, s;  // translation and cos/sin of the block's world pose
+struct alignas(16) PoseXY {
+  double x, y;
+};
+
+// One range reading, landmark-major order: 16 bytes, one load.
+struct alignas(16) ObsRec {
+  double mu;   // measured range
+  uint32_t t;  // timestep it was taken at
+  uint32_t f;  // landmark (dense index)
 };
 
 // Everything a kernel needs, passed by value.
@@ -41,21 +49,21 @@ struct Dev {
   const double* cmu;          // [3][Tcap] control means
   const double* csd;          // [3][Tcap] control std deviations
   const uint32_t* foff;       // [Fcap+1] readings of landmark f: [foff[f], foff[f+1]), time-sorted
-  const uint32_t* ot;         // [Ncap] timestep of a reading (landmark-major order)
-  const double* omu;          // [Ncap] measured range
-  const double* osd;          // [Ncap] its std deviation
-  const uint32_t* ofeat;      // [Ncap] landmark of a reading
+  const ObsRec* orec;         // [Ncap] readings, landmark-major
+  const double* osd;          // [Ncap] std deviation of a reading
+  const double* oisd;         // [Ncap] 1 / std deviation
+  const uint32_t* opiv;       // [Ncap/32+1] timestep of every 32nd reading (search pivots)
   const uint32_t* toff;       // [Tcap+2] arrivals at timestep t: tobs[toff[t] .. toff[t+1])
   const uint32_t* tobs;       // [Ncap] arrival order -> landmark-major position
   const uint32_t* ffirst;     // [Fcap] timestep of a landmark's first reading
   const double* init_u;       // [n_init_u] initialiser draws per landmark, or null
   uint32_t n_init_u;
+  double usig_inv;            // 1/sigma when every reading has the same sigma, else 0
   // ---- chains --------------------------------------------------------------
-  uint32_t C, sh, NBcap;
+  uint32_t C, NTcap;
   double *relx, *rely, *relth;  // [C][Tcap]   relative pose of state edge t
-  double *locx, *locy, *locth;  // [C][Tcap+1] block-local cumulative pose k
-  BlockXf* boff;                // [C][NBcap]  block world offset
-  double* bth;                  // [C][NBcap]  its angle
+  PoseXY* pxy;                  // [C][Tcap+1] world translation of pose k
+  double* pth;                  // [C][Tcap+1] its (unwrapped) angle
   double *sw, *fw;              // [C][Tcap], [C][Fcap] weight trees
   double *fex, *fey;            // [C][Fcap]   landmark estimate relative to its parent pose
   uint32_t* fpar;               // [C][Fcap]   parent reading, as position inside the landmark's list
@@ -77,22 +85,40 @@ struct Dev {
   int32_t uniform_first;
 };
 
-constexpr int kMaxSeg = 256;    // landmark segments evaluated per pass
-constexpr int kActCap = 1024;   // landmarks examined per round (blockDim.x divides it)
+constexpr int kMaxSeg = 256;   // landmark segments evaluated per pass
+constexpr int kActCap = 1024;  // landmarks examined per round (blockDim.x divides it)
 constexpr int kMaxWaves = 16;
+constexpr int kTileShift = 8;  // poses per tile of the rebuild scan = 256
 constexpr uint32_t kMaxRetry = 1u << 16;
 
 enum Op : int { OP_END = 0, OP_EVAL_STATE = 1, OP_EVAL_FEATURE = 2 };
 enum Pending : int { PEND_NONE = 0, PEND_UPDATE = 1, PEND_REPARENT = 2 };
 enum Stage : int { ST_EDGE = 0, ST_ARRIVALS = 1, ST_STEPS = 2, ST_NEXT = 3, ST_END_STEPS = 4, ST_DONE = 5 };
 
+// Diagnostic builds (-DMG_PHASE_TIMING) stamp the shader clock around the phases of a
+// step in lane 0 and sum the differences per chain; normal builds compile the stamps out.
+#ifdef MG_PHASE_TIMING
+#define MG_STAMP(v) const long long v = clock64()
+#define MG_PHASE_ADD(S, slot, a, b)                     \
+  do {                                                  \
+    if (threadIdx.x == 0) (S).phase[slot] += (b) - (a); \
+  } while (0)
+__device__ unsigned long long g_phase_cycles[8];
+#else
+#define MG_STAMP(v)
+#define MG_PHASE_ADD(S, slot, a, b)
+#endif
+
 struct Shared {
+  long long phase[8];
   RngState rng;
   // driver state (lane 0 only)
   int stage;
   uint32_t tn, upto, arr, arr_end, steps_left, steps_per_ts, end_left;
   uint32_t Tcur, nf;
   double ll;
+  double Ws, Wf;  // weight totals, valid while !w_dirty
+  int w_dirty;
   int pending, use_weight;
   double new_pll, old_pll;
   uint32_t rp_obs;
@@ -111,43 +137,23 @@ struct Shared {
   double segw[kMaxSeg][4];  // old landmark (x,y), new landmark (x,y), world frame
   uint32_t wcount[kMaxWaves];
   double red[kMaxWaves];
-  Pose stage_pose[kMaxWaves];
 };
 
 // ---------------------------------------------------------------------------
 // cumulative pose access
 
 MG_DEV Pose world_pose(const Dev& d, uint32_t c, uint32_t k) {
-  const size_t li = size_t(c) * (d.Tcap + 1) + k;
-  const size_t bi = size_t(c) * d.NBcap + (k >> d.sh);
-  const BlockXf xf = d.boff[bi];
-  const double lx = d.locx[li], ly = d.locy[li];
-  return Pose{xf.x + (xf.c * lx - xf.s * ly), xf.y + (xf.s * lx + xf.c * ly), d.bth[bi] + d.locth[li]};
+  const size_t i = size_t(c) * (d.Tcap + 1) + k;
+  const PoseXY p = d.pxy[i];
+  return Pose{p.x, p.y, d.pth[i]};
 }
 
 // Appends pose Tcur+1 = P[Tcur] o rel (lane 0, graph growth).
 MG_DEV void append_pose(const Dev& d, uint32_t c, uint32_t Tcur, const Pose& rel) {
-  const uint32_t k = Tcur + 1;
-  const size_t base = size_t(c) * (d.Tcap + 1);
-  const Pose lprev{d.locx[base + Tcur], d.locy[base + Tcur], d.locth[base + Tcur]};
-  const Pose lnew = compose(lprev, rel);
-  if ((k & ((1u << d.sh) - 1)) == 0) {
-    const size_t bprev = size_t(c) * d.NBcap + (Tcur >> d.sh);
-    const BlockXf xf = d.boff[bprev];
-    const Pose w{xf.x + (xf.c * lnew.x - xf.s * lnew.y), xf.y + (xf.s * lnew.x + xf.c * lnew.y),
-                 d.bth[bprev] + lnew.th};
-    double s, co;
-    sincos(w.th, &s, &co);
-    d.boff[bprev + 1] = BlockXf{w.x, w.y, co, s};
-    d.bth[bprev + 1] = w.th;
-    d.locx[base + k] = 0.0;
-    d.locy[base + k] = 0.0;
-    d.locth[base + k] = 0.0;
-  } else {
-    d.locx[base + k] = lnew.x;
-    d.locy[base + k] = lnew.y;
-    d.locth[base + k] = lnew.th;
-  }
+  const size_t i = size_t(c) * (d.Tcap + 1) + Tcur;
+  const Pose n = compose(world_pose(d, c, Tcur), rel);
+  d.pxy[i + 1] = PoseXY{n.x, n.y};
+  d.pth[i + 1] = n.th;
 }
 
 // ---------------------------------------------------------------------------
@@ -186,42 +192,89 @@ MG_DEV double block_sum(double v, Shared& S) {
   return r;
 }
 
+// |(dx, dy)| to within an ulp or two: v_rsq_f64 seed plus two Goldschmidt
+// steps with fused multiply-adds.  The correctly rounded sqrt the compiler
+// emits costs about twice the instructions, and the reading stream is bound by
+// fp64 instruction issue.  Inputs are lengths in metres; the clamp keeps a
+// zero distance finite.
+MG_DEV double range_of(double dx, double dy) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double x = fmax(fma(dx, dx, dy * dy), 1e-280);
+  const double y = __builtin_amdgcn_rsq(x);
+  double s = x * y, h = 0.5 * y;
+  double r = fma(-h, s, 0.5);
+  s = fma(s, r, s);
+  h = fma(h, r, h);
+  r = fma(-h, s, 0.5);
+  return fma(s, r, s);
+#else
+  return sqrt(dx * dx + dy * dy);
+#endif
+}
+
 // ---------------------------------------------------------------------------
 // The fused observation kernel body: all lanes stream the readings of the
 // prepared segments, gather the pose translation of each reading's timestep
 // and accumulate
 //   FULL == false:  ll(|w_new - t_s|) - ll(|w_old - t_s|)     (mcmc_slam.hpp:487-502)
 //   FULL == true :  ll(|w_old - t_s|) with its constants       (slam_likelihood.hpp:48-54)
+// With z = (r - mu)/sigma the ratio term is -(zn^2 - zo^2)/2, evaluated as
+// (ro - rn) (ro + rn - 2 mu) / (2 sigma^2): the same number without cancelling
+// two large squares.  Per reading: one 16-byte record, one 16-byte pose.
 template <bool FULL>
 MG_DEV double eval_segments(const Dev& d, uint32_t c, const Shared& S, uint32_t nseg) {
   const uint32_t total = S.segpre[nseg];
-  const size_t lbase = size_t(c) * (d.Tcap + 1);
-  const double* __restrict__ locx = d.locx + lbase;
-  const double* __restrict__ locy = d.locy + lbase;
-  const BlockXf* __restrict__ boff = d.boff + size_t(c) * d.NBcap;
-  const uint32_t* __restrict__ ot = d.ot;
-  const double* __restrict__ omu = d.omu;
+  const PoseXY* __restrict__ pxy = d.pxy + size_t(c) * (d.Tcap + 1);
+  const ObsRec* __restrict__ orec = d.orec;
+  const double* __restrict__ oisd = d.oisd;
   const double* __restrict__ osd = d.osd;
+  const bool usig = d.usig_inv > 0.0;
+  const double half_isd2 = 0.5 * d.usig_inv * d.usig_inv;
   double acc = 0.0;
   uint32_t cur = 0;
-  for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) {
-    while (i >= S.segpre[cur + 1]) ++cur;
-    const uint32_t o = S.seglo[cur] + (i - S.segpre[cur]);
-    const uint32_t s = ot[o];
-    const double mu = omu[o];
-    const double sd = osd[o];
-    const BlockXf xf = boff[s >> d.sh];
-    const double lx = locx[s], ly = locy[s];
-    const double px = xf.x + (xf.c * lx - xf.s * ly);
-    const double py = xf.y + (xf.s * lx + xf.c * ly);
-    const double ox = S.segw[cur][0] - px, oy = S.segw[cur][1] - py;
-    const double zo = (sqrt(ox * ox + oy * oy) - mu) / sd;
-    if (FULL) {
-      acc += -0.5 * (zo * zo) - 0.5 * log(2 * kPi) - log(sd);
-    } else {
-      const double nx = S.segw[cur][2] - px, ny = S.segw[cur][3] - py;
-      const double zn = (sqrt(nx * nx + ny * ny) - mu) / sd;
-      acc += (-0.5 * (zn * zn)) - (-0.5 * (zo * zo));
+  // kUnroll readings per lane are in flight at once to cover the latency of the
+  // dependent gather (record -> pose).
+  constexpr int kUnroll = 4;
+  const uint32_t stride = blockDim.x;
+  for (uint32_t i0 = threadIdx.x; i0 < total; i0 += kUnroll * stride) {
+    uint32_t o[kUnroll], sg[kUnroll];
+    bool ok[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const uint32_t i = i0 + u * stride;
+      ok[u] = i < total;
+      if (ok[u]) {
+        while (i >= S.segpre[cur + 1]) ++cur;
+        o[u] = S.seglo[cur] + (i - S.segpre[cur]);
+      } else {
+        o[u] = S.seglo[0];
+      }
+      sg[u] = cur;
+    }
+    ObsRec rec[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) rec[u] = orec[o[u]];
+    PoseXY p[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) p[u] = pxy[rec[u].t];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const double ro = range_of(S.segw[sg[u]][0] - p[u].x, S.segw[sg[u]][1] - p[u].y);
+      double term;
+      if (FULL) {
+        const double sd = osd[o[u]];
+        const double zo = (ro - rec[u].mu) / sd;
+        term = -0.5 * (zo * zo) - 0.5 * log(2 * kPi) - log(sd);
+      } else {
+        const double rn = range_of(S.segw[sg[u]][2] - p[u].x, S.segw[sg[u]][3] - p[u].y);
+        double k = half_isd2;
+        if (!usig) {
+          const double isd = oisd[o[u]];
+          k = 0.5 * isd * isd;
+        }
+        term = (ro - rn) * fma(-2.0, rec[u].mu, ro + rn) * k;
+      }
+      if (ok[u]) acc += term;
     }
   }
   return acc;
@@ -250,6 +303,35 @@ MG_DEV double eval_feature_edge(const Dev& d, uint32_t c, Shared& S, uint32_t f,
   return block_sum(acc, S);
 }
 
+// upper_bound of timestep t in the time-sorted readings [lo, hi).  The pivot
+// table (timestep of every 32nd reading) narrows the range to at most 32
+// readings first, so the search touches a few cache lines instead of
+// log2(hi - lo) scattered ones.
+MG_DEV uint32_t split_readings(const Dev& d, uint32_t lo, uint32_t hi, uint32_t t) {
+  uint32_t a = lo, b = hi;
+  if (hi - lo > 64) {
+    uint32_t pa = (lo + 31) >> 5, pb = (hi + 31) >> 5;  // pivots at positions 32*i in [lo, hi)
+    const uint32_t pa0 = pa;
+    while (pa < pb) {  // first pivot with timestep > t
+      const uint32_t m = (pa + pb) >> 1;
+      if (d.opiv[m] <= t)
+        pa = m + 1;
+      else
+        pb = m;
+    }
+    if (pa > pa0) a = (pa - 1) << 5;  // reading 32*(pa-1) is <= t
+    if ((pa << 5) < hi) b = pa << 5;  // reading 32*pa is > t
+  }
+  while (a < b) {
+    const uint32_t m = (a + b) >> 1;
+    if (d.orec[m].t <= t)
+      a = m + 1;
+    else
+      b = m;
+  }
+  return a;
+}
+
 // State edge (mcmc_slam.hpp:432-466), observation part only.  Replacing the
 // relative pose of edge t by q moves every pose after t rigidly.  For a
 // landmark whose parent pose is after t the landmark moves with it and the
@@ -264,6 +346,9 @@ MG_DEV double eval_state_edge(const Dev& d, uint32_t c, Shared& S, uint32_t t, c
   const Pose qinv = inverse(q);
   const size_t fbase = size_t(c) * d.Fcap;
   double acc = 0.0;
+#ifdef MG_PHASE_TIMING
+  long long tab = clock64();
+#endif
   const uint32_t per = uint32_t(kActCap) / nthr;  // landmarks examined per lane and round (1..16)
   for (uint32_t f0 = 0; f0 < nf; f0 += uint32_t(kActCap)) {
     // A: which landmarks have affected readings?  first <= t < last
@@ -288,16 +373,11 @@ MG_DEV double eval_state_edge(const Dev& d, uint32_t c, Shared& S, uint32_t t, c
       if (tid < nseg) {
         const uint32_t f = S.act[a0 + tid];
         const uint32_t lo = d.foff[f], hi = lo + d.fcnt[fbase + f];
-        uint32_t a = lo, b = hi;  // upper_bound(ot[lo..hi), t)
-        while (a < b) {
-          const uint32_t m = (a + b) >> 1;
-          if (d.ot[m] <= t)
-            a = m + 1;
-          else
-            b = m;
-        }
         const uint32_t pt = d.fpt[fbase + f];
-        const Vec2 w = act(world_pose(d, c, pt), Vec2{d.fex[fbase + f], d.fey[fbase + f]});
+        const Vec2 e{d.fex[fbase + f], d.fey[fbase + f]};
+        const Pose Pp = world_pose(d, c, pt);
+        const uint32_t a = split_readings(d, lo, hi, t);
+        const Vec2 w = act(Pp, e);
         Vec2 wn;
         uint32_t slo, shi;
         if (t < pt) {  // landmark hangs off a pose that moves
@@ -322,9 +402,16 @@ MG_DEV double eval_state_edge(const Dev& d, uint32_t c, Shared& S, uint32_t t, c
       if (tid == 0) S.segpre[0] = 0;
       __syncthreads();
       units += total;
+      MG_STAMP(tc0);
+      MG_PHASE_ADD(S, 1, tab, tc0);
       // C: stream the affected readings
       acc += eval_segments<false>(d, c, S, nseg);
       __syncthreads();
+      MG_STAMP(tc1);
+      MG_PHASE_ADD(S, 2, tc0, tc1);
+#ifdef MG_PHASE_TIMING
+      tab = tc1;
+#endif
     }
   }
   return block_sum(acc, S);
@@ -332,45 +419,22 @@ MG_DEV double eval_state_edge(const Dev& d, uint32_t c, Shared& S, uint32_t t, c
 
 // Accepted state edge t <- q: P'[k] = P[k] (k <= t), D o P[k] (k > t) with
 // D = P[t] o q o P[t+1]^-1, applied as a rotation about the old P[t+1] so no
-// large coordinates cancel.  Inside the block of pose t+1 the block-local
-// poses are updated, after it only the block offsets.
+// large coordinates cancel: P'[k].t = A.t + R(D.th) (P[k].t - P[t+1].t) with
+// A = P[t] o q the new pose t+1.
 MG_DEV void commit_state_edge(const Dev& d, uint32_t c, uint32_t t, const Pose& q, uint32_t Tcur) {
-  const uint32_t tid = threadIdx.x, nthr = blockDim.x;
-  const uint32_t bsz = 1u << d.sh;
-  const uint32_t k1 = t + 1, b1 = k1 >> d.sh, k0 = b1 << d.sh;
-  const bool at_block_start = (k1 == k0);
-  const size_t lbase = size_t(c) * (d.Tcap + 1);
-  const size_t bbase = size_t(c) * d.NBcap;
+  const uint32_t k1 = t + 1;
+  const size_t base = size_t(c) * (d.Tcap + 1);
   const Pose Pt = world_pose(d, c, t), Pt1 = world_pose(d, c, k1);
   const Pose A = compose(Pt, q);
   const double Dth = q.th - d.relth[size_t(c) * d.Tcap + t];
   double sD, cD;
   sincos(Dth, &sD, &cD);
-  Pose Lt1 = pose_identity(), Al = pose_identity();
-  if (!at_block_start) {
-    const Pose Lt{d.locx[lbase + t], d.locy[lbase + t], d.locth[lbase + t]};
-    Lt1 = Pose{d.locx[lbase + k1], d.locy[lbase + k1], d.locth[lbase + k1]};
-    Al = compose(Lt, q);
-  }
-  __syncthreads();  // every lane holds the old values before anything is overwritten
-  if (!at_block_start) {
-    const uint32_t kend = (k0 + bsz - 1) < Tcur ? (k0 + bsz - 1) : Tcur;
-    for (uint32_t k = k1 + tid; k <= kend; k += nthr) {
-      const double lx = d.locx[lbase + k] - Lt1.x, ly = d.locy[lbase + k] - Lt1.y;
-      d.locx[lbase + k] = Al.x + (cD * lx - sD * ly);
-      d.locy[lbase + k] = Al.y + (sD * lx + cD * ly);
-      d.locth[lbase + k] += Dth;
-    }
-  }
-  const uint32_t bfirst = at_block_start ? b1 : b1 + 1, blast = Tcur >> d.sh;
-  for (uint32_t b = bfirst + tid; b <= blast; b += nthr) {
-    const BlockXf xf = d.boff[bbase + b];
-    const double dx = xf.x - Pt1.x, dy = xf.y - Pt1.y;
-    const double nth = d.bth[bbase + b] + Dth;
-    double s, co;
-    sincos(nth, &s, &co);
-    d.boff[bbase + b] = BlockXf{A.x + (cD * dx - sD * dy), A.y + (sD * dx + cD * dy), co, s};
-    d.bth[bbase + b] = nth;
+  __syncthreads();  // every lane holds the old pivot before anything is overwritten
+  for (uint32_t k = k1 + threadIdx.x; k <= Tcur; k += blockDim.x) {
+    const PoseXY p = d.pxy[base + k];
+    const double dx = p.x - Pt1.x, dy = p.y - Pt1.y;
+    d.pxy[base + k] = PoseXY{A.x + (cD * dx - sD * dy), A.y + (sD * dx + cD * dy)};
+    d.pth[base + k] += Dth;
   }
 }
 
@@ -416,8 +480,19 @@ MG_DEV void driver_add_state_edge(const Dev& d, uint32_t c, Shared& S) {
   append_pose(d, c, t, est);
   const double lp = control_log_pdf(mu, sd, est);
   wt::push_back(d.sw + size_t(c) * d.Tcap, t, edge_weight_from_log_pdf(lp, 3.0, nullptr));
+  S.w_dirty = 1;
   S.ll += lp;
   S.Tcur = t + 1;
+}
+
+// Weight totals of both trees (mcmc_slam.hpp:342-343, :400-401).  They only
+// change when a weight changes, so they are kept until then; recomputing them
+// gives bit-identical values.
+MG_DEV void refresh_totals(const Dev& d, uint32_t c, Shared& S) {
+  if (!S.w_dirty) return;
+  S.Ws = wt::total(d.sw + size_t(c) * d.Tcap, S.Tcur);
+  S.Wf = wt::total(d.fw + size_t(c) * d.Fcap, S.nf);
+  S.w_dirty = 0;
 }
 
 // Selection and proposal of one update (mcmc_slam.hpp:339-368, :375-382).
@@ -425,7 +500,8 @@ MG_DEV void driver_add_state_edge(const Dev& d, uint32_t c, Shared& S) {
 MG_DEV bool driver_begin_update(const Dev& d, uint32_t c, Shared& S) {
   const double* sw = d.sw + size_t(c) * d.Tcap;
   const double* fw = d.fw + size_t(c) * d.Fcap;
-  const double Ws = wt::total(sw, S.Tcur), Wf = wt::total(fw, S.nf);
+  refresh_totals(d, c, S);
+  const double Ws = S.Ws, Wf = S.Wf;
   if (Ws == 0 && Wf == 0) return false;
   uint32_t retry = 0;
   if ((Ws + Wf) * rng_uniform(S.rng) < Ws) {
@@ -462,7 +538,7 @@ MG_DEV bool driver_begin_update(const Dev& d, uint32_t c, Shared& S) {
     }
     const size_t fi = size_t(c) * d.Fcap + f;
     const uint32_t po = d.foff[f] + d.fpar[fi];
-    const double mu = d.omu[po], sd = d.osd[po];
+    const double mu = d.orec[po].mu, sd = d.osd[po];
     double r, u;
     if (d.uniform_first) {
       u = rng_uniform(S.rng);
@@ -487,7 +563,7 @@ MG_DEV bool driver_begin_update(const Dev& d, uint32_t c, Shared& S) {
 
 // The rest of mcmc_slam::update(EdgeType&&, bool) (:385-418) once the
 // observation part of the log ratio is known.  Returns the accept decision;
-// pose tables of an accepted state edge are moved afterwards by all lanes.
+// the pose table of an accepted state edge is moved afterwards by all lanes.
 MG_DEV bool driver_finish_update(const Dev& d, uint32_t c, Shared& S, double obs_ratio) {
   const bool is_state = (S.op == OP_EVAL_STATE);
   const double dim = is_state ? 3.0 : 2.0;
@@ -503,7 +579,8 @@ MG_DEV bool driver_finish_update(const Dev& d, uint32_t c, Shared& S, double obs
   if (S.use_weight) {
     double old_log_weight;
     const double old_weight = edge_weight_from_log_pdf(S.old_pll, dim, &old_log_weight);
-    const double weight_sum = wt::total(sw, S.Tcur) + wt::total(fw, S.nf);
+    refresh_totals(d, c, S);
+    const double weight_sum = S.Ws + S.Wf;
     normaliser += (new_weight - old_weight) / weight_sum;
     accept_log_ratio += new_log_weight - old_log_weight;
   }
@@ -511,14 +588,15 @@ MG_DEV bool driver_finish_update(const Dev& d, uint32_t c, Shared& S, double obs
   if (accept) {
     if (is_state) {
       wt::set(sw, S.Tcur, S.idx, new_weight);
-      // the relative pose itself is stored by commit_state_edge's caller after
-      // the pose tables have been moved (they need the old angle)
+      // the relative pose itself is stored after commit_state_edge has moved
+      // the pose table (that needs the old angle)
     } else {
       const size_t fi = size_t(c) * d.Fcap + S.idx;
       d.fex[fi] = S.q[0];
       d.fey[fi] = S.q[1];
       wt::set(fw, S.nf, S.idx, new_weight);
     }
+    S.w_dirty = 1;
     S.ll += log_ratio;
   }
   write_trace(d, c, S, is_state ? 0 : 1, S.idx, S.q, log_ratio, accept ? 1 : 0);
@@ -528,10 +606,11 @@ MG_DEV bool driver_finish_update(const Dev& d, uint32_t c, Shared& S, double obs
 // One arrival during growth (mcmc_slam.hpp:283-331).  Returns true when a
 // re-parenting update was posted and needs the workgroup.
 MG_DEV bool driver_arrival(const Dev& d, uint32_t c, Shared& S, uint32_t o) {
-  const uint32_t f = d.ofeat[o];
+  const ObsRec rec = d.orec[o];
+  const uint32_t f = rec.f;
   const size_t fi = size_t(c) * d.Fcap + f;
   const uint32_t t = S.tn;
-  const double mu = d.omu[o], sd = d.osd[o];
+  const double mu = rec.mu, sd = d.osd[o];
   if (o == d.foff[f]) {  // first reading of this landmark: add_feature_edge, :248-270
     const double u = (d.init_u && f < d.n_init_u) ? d.init_u[f] : rng_uniform(S.rng);
     const Vec2 est = polar(mu, u * 2 * kPi);
@@ -543,6 +622,7 @@ MG_DEV bool driver_arrival(const Dev& d, uint32_t c, Shared& S, uint32_t o) {
     d.flast[fi] = t;
     wt::push_back(d.fw + size_t(c) * d.Fcap, f,
                   edge_weight_from_log_pdf(range_proposal_log_pdf(mu, sd, est), 2.0, nullptr));
+    S.w_dirty = 1;
     S.ll += range_log_pdf(mu, sd, vec_norm(est));
     S.nf = f + 1;
     return false;
@@ -554,7 +634,7 @@ MG_DEV bool driver_arrival(const Dev& d, uint32_t c, Shared& S, uint32_t o) {
   const Vec2 w = act(world_pose(d, c, pt), Vec2{d.fex[fi], d.fey[fi]});
   const Vec2 est = act_inverse(world_pose(d, c, t), w);
   S.ll += range_log_pdf(mu, sd, vec_norm(est));
-  const double par_mu = d.omu[d.foff[f] + d.fpar[fi]];
+  const double par_mu = d.orec[d.foff[f] + d.fpar[fi]].mu;
   if (fabs(mu) < fabs(par_mu)) {  // more_accurate_than, range_bearing_model.hpp:141-143
     d.fpar[fi] = rel;
     d.fpt[fi] = t;
@@ -657,7 +737,9 @@ MG_DEV void chain_state_load(const Dev& d, uint32_t c, Shared& S) {
     S.n_state = 0;
     S.n_moved = 0;
     S.failed = 0;
+    S.w_dirty = 1;
     S.pending = PEND_NONE;
+    for (int i = 0; i < 8; ++i) S.phase[i] = 0;
   }
 }
 MG_DEV void chain_state_store(const Dev& d, uint32_t c, Shared& S) {
@@ -694,9 +776,13 @@ __global__ void advance_kernel(Dev d, uint32_t first_tn, uint32_t Tcur0, uint32_
     S.stage = grow ? ST_EDGE : ST_END_STEPS;
   }
   __syncthreads();
+  MG_STAMP(tk0);
   for (;;) {
+    MG_STAMP(td0);
     if (threadIdx.x == 0) driver_advance(d, c, S);
     __syncthreads();
+    MG_STAMP(td1);
+    MG_PHASE_ADD(S, 0, td0, td1);
     const int op = S.op;
     if (op == OP_END) break;
     const uint32_t idx = S.idx;
@@ -708,6 +794,8 @@ __global__ void advance_kernel(Dev d, uint32_t first_tn, uint32_t Tcur0, uint32_
       r = eval_state_edge(d, c, S, idx, q, nf, units);
     else
       r = eval_feature_edge(d, c, S, idx, Vec2{q.x, q.y}, units);
+    MG_STAMP(te1);
+    if (op != OP_EVAL_STATE) MG_PHASE_ADD(S, 3, td1, te1);
     if (threadIdx.x == 0) {
       S.n_units += units;
       if (op == OP_EVAL_STATE) ++S.n_state;
@@ -720,11 +808,14 @@ __global__ void advance_kernel(Dev d, uint32_t first_tn, uint32_t Tcur0, uint32_
         const size_t fi = size_t(c) * d.Fcap + idx;
         wt::set(d.fw + size_t(c) * d.Fcap, S.nf, idx,
                 edge_weight_from_log_pdf(
-                    range_proposal_log_pdf(d.omu[o], d.osd[o], Vec2{d.fex[fi], d.fey[fi]}), 2.0, nullptr));
+                    range_proposal_log_pdf(d.orec[o].mu, d.osd[o], Vec2{d.fex[fi], d.fey[fi]}), 2.0, nullptr));
+        S.w_dirty = 1;
       }
       S.pending = PEND_NONE;
     }
     __syncthreads();
+    MG_STAMP(tf1);
+    MG_PHASE_ADD(S, 4, te1, tf1);
     if (op == OP_EVAL_STATE && S.accept) {
       commit_state_edge(d, c, idx, q, Tcur);
       if (threadIdx.x == 0) {
@@ -732,19 +823,25 @@ __global__ void advance_kernel(Dev d, uint32_t first_tn, uint32_t Tcur0, uint32_
         d.relx[ri] = q.x;
         d.rely[ri] = q.y;
         d.relth[ri] = q.th;
-        // poses rewritten: the rest of pose idx+1's block plus the later block offsets
-        const uint32_t k1 = idx + 1, kend = ((k1 >> d.sh) << d.sh) + (1u << d.sh) - 1;
-        S.n_moved += ((kend < Tcur ? kend : Tcur) - k1 + 1) + ((Tcur >> d.sh) - (k1 >> d.sh));
+        S.n_moved += Tcur - idx;  // poses idx+1 .. Tcur rewritten
       }
     }
     __syncthreads();
+    MG_STAMP(tg1);
+    MG_PHASE_ADD(S, 5, tf1, tg1);
   }
+  MG_STAMP(tk1);
+  MG_PHASE_ADD(S, 6, tk0, tk1);
+#ifdef MG_PHASE_TIMING
+  if (threadIdx.x == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_phase_cycles[i], (unsigned long long)S.phase[i]);
+#endif
   chain_state_store(d, c, S);
 }
 
 // edge_log_likelihood_ratio for a caller-supplied proposal; grid = 1.
 __global__ void eval_kernel(Dev d, uint32_t c, int kind, uint32_t idx, double q0, double q1, double q2,
-                            uint32_t Tcur, double* out) {
+                            double* out) {
   __shared__ Shared S;
   unsigned long long units = 0;
   double r;
@@ -761,7 +858,6 @@ __global__ void eval_kernel(Dev d, uint32_t c, int kind, uint32_t idx, double q0
   } else {
     r = eval_feature_edge(d, c, S, idx, Vec2{q0, q1}, units);
   }
-  (void)Tcur;
   if (threadIdx.x == 0) *out = r;
 }
 
@@ -788,67 +884,64 @@ __global__ void commit_kernel(Dev d, uint32_t c, int kind, uint32_t idx, double 
   }
 }
 
-// ---- cumulative pose rebuild: two-level SE(2) scan --------------------------
-// level 1: grid = (blocks of poses, chains), block = 2^sh lanes.  Lane j of
-// tile b composes rel[k0 .. k0+j]; the tile total goes to `tot`.
-__global__ void scan_local_kernel(Dev d, uint32_t Tcur, Pose* tot) {
+// ---- cumulative pose rebuild: three-pass SE(2) scan ---------------------------
+// pass 1: grid = (tiles, chains), block = 256.  Lane j of tile b composes
+// rel[256 b .. 256 b + j] and leaves it, still tile-local, in pose slot
+// 256 b + j + 1; the tile total goes to `tot`.
+__global__ void scan_tiles_kernel(Dev d, uint32_t Tcur, Pose* tot) {
   __shared__ Pose stage[kMaxWaves];
   const uint32_t c = blockIdx.y, b = blockIdx.x, j = threadIdx.x;
-  const uint32_t k0 = b << d.sh, k = k0 + j;
-  const size_t rbase = size_t(c) * d.Tcap, lbase = size_t(c) * (d.Tcap + 1);
+  const uint32_t k = (b << kTileShift) + j;
+  const size_t rbase = size_t(c) * d.Tcap, pbase = size_t(c) * (d.Tcap + 1);
   Pose v = pose_identity();
   if (k < Tcur) v = Pose{d.relx[rbase + k], d.rely[rbase + k], d.relth[rbase + k]};
   Pose total;
   const Pose inc = block_scan_inclusive(v, PoseOp{}, stage, total);
-  if (j == 0) {
-    d.locx[lbase + k0] = 0.0;
-    d.locy[lbase + k0] = 0.0;
-    d.locth[lbase + k0] = 0.0;
+  if (k < Tcur) {
+    d.pxy[pbase + k + 1] = PoseXY{inc.x, inc.y};
+    d.pth[pbase + k + 1] = inc.th;
   }
-  if (j + 1 < blockDim.x && k + 1 <= Tcur) {
-    d.locx[lbase + k + 1] = inc.x;
-    d.locy[lbase + k + 1] = inc.y;
-    d.locth[lbase + k + 1] = inc.th;
-  }
-  if (j == blockDim.x - 1) tot[size_t(c) * d.NBcap + b] = total;
+  if (j == 0) tot[size_t(c) * d.NTcap + b] = total;
 }
 
-// level 2: grid = chains.  Exclusive scan of the tile totals -> block offsets.
-__global__ void scan_offsets_kernel(Dev d, uint32_t nblocks, const Pose* tot) {
+// pass 2: grid = chains.  Exclusive scan of the tile totals, in place: tot[b]
+// becomes the world pose at the start of tile b.
+__global__ void scan_offsets_kernel(Dev d, uint32_t ntiles, Pose* tot) {
   __shared__ Pose stage[kMaxWaves];
+  __shared__ Pose incl[256];
   const uint32_t c = blockIdx.x;
-  const size_t bbase = size_t(c) * d.NBcap;
+  Pose* t = tot + size_t(c) * d.NTcap;
   Pose carry = pose_identity();
-  if (threadIdx.x == 0) {
-    d.boff[bbase] = BlockXf{0.0, 0.0, 1.0, 0.0};
-    d.bth[bbase] = 0.0;
-  }
-  for (uint32_t b0 = 0; b0 + 1 < nblocks; b0 += blockDim.x) {
+  for (uint32_t b0 = 0; b0 < ntiles; b0 += blockDim.x) {
     const uint32_t b = b0 + threadIdx.x;
     Pose v = pose_identity();
-    if (b + 1 < nblocks) v = tot[bbase + b];
+    if (b < ntiles) v = t[b];
     Pose total;
-    Pose inc = block_scan_inclusive(v, PoseOp{}, stage, total);
-    inc = compose(carry, inc);
-    if (b + 1 < nblocks) {
-      double s, co;
-      sincos(inc.th, &s, &co);
-      d.boff[bbase + b + 1] = BlockXf{inc.x, inc.y, co, s};
-      d.bth[bbase + b + 1] = inc.th;
-    }
+    incl[threadIdx.x] = block_scan_inclusive(v, PoseOp{}, stage, total);
+    __syncthreads();
+    // exclusive value of lane j = carry o inclusive value of lane j-1
+    const Pose excl = threadIdx.x == 0 ? carry : compose(carry, incl[threadIdx.x - 1]);
+    __syncthreads();
+    if (b < ntiles) t[b] = excl;
     carry = compose(carry, total);
   }
 }
 
-// World poses of one chain, k = 0..Tcur, as [k][3].
-__global__ void materialize_kernel(Dev d, uint32_t c, uint32_t Tcur, double* out) {
-  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k <= Tcur) {
-    const Pose p = world_pose(d, c, k);
-    out[3 * size_t(k)] = p.x;
-    out[3 * size_t(k) + 1] = p.y;
-    out[3 * size_t(k) + 2] = p.th;
+// pass 3: grid = (tiles, chains), block = 256.  P[k] = offset[tile] o local[k].
+__global__ void scan_apply_kernel(Dev d, uint32_t Tcur, const Pose* tot) {
+  const uint32_t c = blockIdx.y, b = blockIdx.x;
+  const uint32_t k = (b << kTileShift) + threadIdx.x;  // relative-pose index; pose slot k + 1
+  const size_t pbase = size_t(c) * (d.Tcap + 1);
+  if (b == 0 && threadIdx.x == 0) {
+    d.pxy[pbase] = PoseXY{0.0, 0.0};
+    d.pth[pbase] = 0.0;
   }
+  if (k >= Tcur || b == 0) return;  // tile 0 is already in world coordinates
+  const Pose off = tot[size_t(c) * d.NTcap + b];
+  const PoseXY l = d.pxy[pbase + k + 1];
+  const Pose w = compose(off, Pose{l.x, l.y, d.pth[pbase + k + 1]});
+  d.pxy[pbase + k + 1] = PoseXY{w.x, w.y};
+  d.pth[pbase + k + 1] = w.th;
 }
 
 // World landmark positions and plain edge weights of one chain.
@@ -866,7 +959,7 @@ __global__ void readout_kernel(Dev d, uint32_t c, uint32_t Tcur, double* feat_wo
   if (i < Tcur) state_w[i] = wt::get(d.sw + size_t(c) * d.Tcap, i);
 }
 
-// slam_log_likelihood (src/slam/slam_likelihood.hpp:26-58); grid = chains.
+// slam_log_likelihood (src/slam/slam_likelihood.hpp:26-58); grid = chains from `first`.
 __global__ void full_ll_kernel(Dev d, uint32_t first, uint32_t Tcur, double* out) {
   __shared__ Shared S;
   const uint32_t c = first + blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
@@ -923,11 +1016,8 @@ __global__ void init_chains_kernel(Dev d, const uint32_t* seeds) {
   d.n_moved[c] = 0;
   d.errflag[c] = 0;
   if (d.trace_n) d.trace_n[c] = 0;
-  d.locx[size_t(c) * (d.Tcap + 1)] = 0.0;
-  d.locy[size_t(c) * (d.Tcap + 1)] = 0.0;
-  d.locth[size_t(c) * (d.Tcap + 1)] = 0.0;
-  d.boff[size_t(c) * d.NBcap] = BlockXf{0.0, 0.0, 1.0, 0.0};
-  d.bth[size_t(c) * d.NBcap] = 0.0;
+  d.pxy[size_t(c) * (d.Tcap + 1)] = PoseXY{0.0, 0.0};
+  d.pth[size_t(c) * (d.Tcap + 1)] = 0.0;
 }
 
 __global__ void summaries_kernel(Dev d, mcmcgpu_chain_summary* out) {
@@ -967,7 +1057,7 @@ __global__ void reweigh_kernel(Dev d, uint32_t first, uint32_t Tcur) {
   for (uint32_t f = threadIdx.x; f < nf; f += blockDim.x) {
     const size_t fi = size_t(c) * d.Fcap + f;
     const uint32_t po = d.foff[f] + d.fpar[fi];
-    const double lp = range_proposal_log_pdf(d.omu[po], d.osd[po], Vec2{d.fex[fi], d.fey[fi]});
+    const double lp = range_proposal_log_pdf(d.orec[po].mu, d.osd[po], Vec2{d.fex[fi], d.fey[fi]});
     fw[f] = edge_weight_from_log_pdf(lp, 2.0, nullptr);
   }
   build_tree_levels(fw, nf);

@@ -32,7 +32,7 @@ struct mcmcgpu_ctx {
   bool own_stream = false;
   Dev d{};
   std::vector<void*> allocations;
-  Pose* scan_tot = nullptr;  // [C][NBcap] tile totals of the rebuild scan
+  Pose* scan_tot = nullptr;  // [C][NTcap] tile totals / offsets of the rebuild scan
   uint32_t* seed_stage = nullptr;  // [C]
   double* scratch = nullptr;  // readout staging: max(3*(Tcap+1), ...) doubles
   size_t scratch_doubles = 0;
@@ -98,10 +98,11 @@ int check_device_flags(mcmcgpu_handle h) {
 
 int rebuild_impl(mcmcgpu_handle h) {
   const uint32_t Tcur = edges_grown(h);
-  const uint32_t nblocks = (Tcur >> h->d.sh) + 1;
-  hipLaunchKernelGGL(scan_local_kernel, dim3(nblocks, h->chains), dim3(1u << h->d.sh), 0, h->stream, h->d, Tcur,
-                     h->scan_tot);
-  hipLaunchKernelGGL(scan_offsets_kernel, dim3(h->chains), dim3(256), 0, h->stream, h->d, nblocks, h->scan_tot);
+  const uint32_t ntiles = std::max<uint32_t>(1, (Tcur + (1u << kTileShift) - 1) >> kTileShift);
+  const dim3 tiles(ntiles, h->chains), lanes(1u << kTileShift);
+  hipLaunchKernelGGL(scan_tiles_kernel, tiles, lanes, 0, h->stream, h->d, Tcur, h->scan_tot);
+  hipLaunchKernelGGL(scan_offsets_kernel, dim3(h->chains), dim3(256), 0, h->stream, h->d, ntiles, h->scan_tot);
+  hipLaunchKernelGGL(scan_apply_kernel, tiles, lanes, 0, h->stream, h->d, Tcur, h->scan_tot);
   HIP_TRY(h, hipGetLastError());
   return 0;
 }
@@ -115,8 +116,6 @@ const char* mcmcgpu_last_error(mcmcgpu_handle h) { return h ? h->error.c_str() :
 int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out) {
   if (!cfg || !out) return fail(nullptr, MCMCGPU_ERR_ARGUMENT, "null argument");
   if (cfg->max_chains == 0) return fail(nullptr, MCMCGPU_ERR_ARGUMENT, "max_chains must be positive");
-  const uint32_t sh = cfg->block_shift ? cfg->block_shift : 8;
-  if (sh < 6 || sh > 10) return fail(nullptr, MCMCGPU_ERR_ARGUMENT, "block_shift must be in [6, 10]");
   const uint32_t nthr = cfg->threads_per_chain ? cfg->threads_per_chain : 256;
   if (nthr < 64 || nthr > 1024 || !is_pow2(nthr))
     return fail(nullptr, MCMCGPU_ERR_ARGUMENT, "threads_per_chain must be a power of two in [64, 1024]");
@@ -145,8 +144,7 @@ int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out) {
   d.Fcap = std::max<uint32_t>(cfg->max_features, 1);
   d.Ncap = std::max<uint32_t>(cfg->max_observations, 1);
   d.C = 0;
-  d.sh = sh;
-  d.NBcap = (d.Tcap >> sh) + 1;
+  d.NTcap = (d.Tcap >> kTileShift) + 1;
   d.uniform_first = cfg->feature_uniform_first ? 1 : 0;
   d.trace_cap = cfg->trace_capacity;
   const size_t C = cfg->max_chains;
@@ -158,10 +156,10 @@ int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out) {
   ALLOC(d.cmu, 3 * size_t(d.Tcap));
   ALLOC(d.csd, 3 * size_t(d.Tcap));
   ALLOC(d.foff, size_t(d.Fcap) + 1);
-  ALLOC(d.ot, d.Ncap);
-  ALLOC(d.omu, d.Ncap);
+  ALLOC(d.orec, d.Ncap);
+  ALLOC(d.oisd, d.Ncap);
+  ALLOC(d.opiv, size_t(d.Ncap) / 32 + 2);
   ALLOC(d.osd, d.Ncap);
-  ALLOC(d.ofeat, d.Ncap);
   ALLOC(d.toff, size_t(d.Tcap) + 2);
   ALLOC(d.tobs, d.Ncap);
   ALLOC(d.ffirst, d.Fcap);
@@ -169,11 +167,8 @@ int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out) {
   ALLOC(d.relx, C * d.Tcap);
   ALLOC(d.rely, C * d.Tcap);
   ALLOC(d.relth, C * d.Tcap);
-  ALLOC(d.locx, C * (size_t(d.Tcap) + 1));
-  ALLOC(d.locy, C * (size_t(d.Tcap) + 1));
-  ALLOC(d.locth, C * (size_t(d.Tcap) + 1));
-  ALLOC(d.boff, C * d.NBcap);
-  ALLOC(d.bth, C * d.NBcap);
+  ALLOC(d.pxy, C * (size_t(d.Tcap) + 1));
+  ALLOC(d.pth, C * (size_t(d.Tcap) + 1));
   ALLOC(d.sw, C * d.Tcap);
   ALLOC(d.fw, C * d.Fcap);
   ALLOC(d.fex, C * d.Fcap);
@@ -196,7 +191,7 @@ int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out) {
   ALLOC(d.errflag, C);
   ALLOC(d.trace_n, C);
   if (d.trace_cap) ALLOC(d.trace, C * d.trace_cap);
-  ALLOC(h->scan_tot, C * d.NBcap);
+  ALLOC(h->scan_tot, C * d.NTcap);
   ALLOC(h->seed_stage, C);
   h->scratch_doubles = 5 * (size_t(d.Tcap) + 1) + 4 * size_t(d.Fcap) + 16;
   ALLOC(h->scratch, h->scratch_doubles);
@@ -264,7 +259,9 @@ int mcmcgpu_upload_problem(mcmcgpu_handle h, uint32_t T, const double* ctrl_mean
   if (seen != F) return fail(h, MCMCGPU_ERR_ARGUMENT, "F does not match the landmarks that appear in the readings");
   for (uint32_t f = 0; f < F; ++f) foff[f + 1] += foff[f];
   for (uint32_t t = 0; t <= T; ++t) toff[t + 1] += toff[t];
-  std::vector<uint32_t> fill(foff.begin(), foff.end() - 1), ot(N), ofeat(N), tobs(N), ffirst(F, 0);
+  std::vector<uint32_t> fill(foff.begin(), foff.end() - 1), ot(N), tobs(N), ffirst(F, 0), opiv(size_t(N) / 32 + 1, 0);
+  std::vector<ObsRec> orec(N);
+  std::vector<double> oisd(N);
   std::vector<double> omu(N), osd(N);
   for (uint32_t i = 0; i < N; ++i) {
     const uint32_t f = obs_feature[i];
@@ -275,7 +272,8 @@ int mcmcgpu_upload_problem(mcmcgpu_handle h, uint32_t T, const double* ctrl_mean
     ot[pos] = obs_timestep[i];
     omu[pos] = obs_mean[i];
     osd[pos] = obs_stddev[i];
-    ofeat[pos] = f;
+    orec[pos] = ObsRec{obs_mean[i], obs_timestep[i], f};
+    oisd[pos] = 1.0 / obs_stddev[i];
     tobs[i] = pos;  // arrivals are already grouped by timestep, in order
   }
   auto up = [&](const void* dst, const void* src, size_t bytes) {
@@ -285,16 +283,20 @@ int mcmcgpu_upload_problem(mcmcgpu_handle h, uint32_t T, const double* ctrl_mean
   HIP_TRY(h, up(d.csd, csd.data(), csd.size() * sizeof(double)));
   HIP_TRY(h, up(d.foff, foff.data(), foff.size() * sizeof(uint32_t)));
   HIP_TRY(h, up(d.toff, toff.data(), toff.size() * sizeof(uint32_t)));
-  HIP_TRY(h, up(d.ot, ot.data(), size_t(N) * sizeof(uint32_t)));
-  HIP_TRY(h, up(d.ofeat, ofeat.data(), size_t(N) * sizeof(uint32_t)));
+  for (size_t i = 0; 32 * i < N; ++i) opiv[i] = ot[32 * i];
+  bool uniform_sigma = N > 0;
+  for (uint32_t i = 1; i < N; ++i) uniform_sigma = uniform_sigma && obs_stddev[i] == obs_stddev[0];
+  HIP_TRY(h, up(d.orec, orec.data(), size_t(N) * sizeof(ObsRec)));
+  HIP_TRY(h, up(d.oisd, oisd.data(), size_t(N) * sizeof(double)));
+  HIP_TRY(h, up(d.opiv, opiv.data(), opiv.size() * sizeof(uint32_t)));
   HIP_TRY(h, up(d.tobs, tobs.data(), size_t(N) * sizeof(uint32_t)));
-  HIP_TRY(h, up(d.omu, omu.data(), size_t(N) * sizeof(double)));
   HIP_TRY(h, up(d.osd, osd.data(), size_t(N) * sizeof(double)));
   HIP_TRY(h, up(d.ffirst, ffirst.data(), size_t(F) * sizeof(uint32_t)));
   HIP_TRY(h, hipStreamSynchronize(h->stream));  // host staging vectors die here
   d.T = T;
   d.N = N;
   d.F = F;
+  d.usig_inv = uniform_sigma ? 1.0 / obs_stddev[0] : 0.0;
   h->h_foff = foff;
   h->h_ot = ot;
   h->h_omu = omu;
@@ -378,7 +380,7 @@ int mcmcgpu_eval_llr(mcmcgpu_handle h, uint32_t chain, int kind, uint32_t index,
     if (index >= nf) return fail(h, MCMCGPU_ERR_ARGUMENT, "landmark not yet observed by this chain");
   }
   hipLaunchKernelGGL(eval_kernel, dim3(1), dim3(h->nthreads), 0, h->stream, h->d, chain, kind, index, proposed[0],
-                     proposed[1], proposed[2], edges_grown(h), h->scratch);
+                     proposed[1], proposed[2], h->scratch);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemcpyAsync(out, h->scratch, sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -477,11 +479,16 @@ int mcmcgpu_get_state(mcmcgpu_handle h, uint32_t chain, double* rel_poses, doubl
     }
   }
   if (cum_poses) {
-    hipLaunchKernelGGL(materialize_kernel, dim3((T + 1 + 255) / 256), dim3(256), 0, h->stream, d, chain, T,
-                       h->scratch);
-    HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, down(cum_poses, h->scratch, sizeof(double) * 3 * (size_t(T) + 1)));
+    std::vector<PoseXY> xy(size_t(T) + 1);
+    std::vector<double> th(size_t(T) + 1);
+    HIP_TRY(h, down(xy.data(), d.pxy + size_t(chain) * (d.Tcap + 1), sizeof(PoseXY) * (size_t(T) + 1)));
+    HIP_TRY(h, down(th.data(), d.pth + size_t(chain) * (d.Tcap + 1), sizeof(double) * (size_t(T) + 1)));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (size_t k = 0; k <= T; ++k) {
+      cum_poses[3 * k] = xy[k].x;
+      cum_poses[3 * k + 1] = xy[k].y;
+      cum_poses[3 * k + 2] = th[k];
+    }
   }
   if (feat_world || state_weights || feat_weights) {
     double* dworld = h->scratch;                  // [2*Fcap]
@@ -691,6 +698,24 @@ void mcmcgpu_uniform_sequence(uint32_t seed, uint32_t n, double* out) {
   RngState r;
   rng_seed(r, seed);
   for (uint32_t i = 0; i < n; ++i) out[i] = rng_uniform(r);
+}
+
+int mcmcgpu_debug_phase_cycles(mcmcgpu_handle h, uint64_t out[8], int reset) {
+  if (!h || !out) return MCMCGPU_ERR_ARGUMENT;
+#ifdef MG_PHASE_TIMING
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), 8 * sizeof(uint64_t)));
+  if (reset) {
+    const uint64_t zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIP_TRY(h, hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), zero, sizeof zero));
+  }
+  return 0;
+#else
+  (void)reset;
+  for (int i = 0; i < 8; ++i) out[i] = 0;
+  return fail(h, MCMCGPU_ERR_STATE, "library was built without -DMG_PHASE_TIMING");
+#endif
 }
 
 int mcmcgpu_selftest_scan(int32_t device, uint32_t n, int32_t p, const int32_t* a, const int32_t* b, int32_t* out_a,
