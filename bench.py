@@ -39,7 +39,8 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--chains", type=int, default=1024, help="chains per GPU")
-    ap.add_argument("--updates-per-step", type=int, default=8)
+    ap.add_argument("--updates-per-step", type=int, default=100,
+                    help="updates per chain per launch; 100 = the report interval of multi_mcmc.hpp:125")
     ap.add_argument("--timesteps", type=int, default=100_000)
     ap.add_argument("--landmarks", type=int, default=1000)
     ap.add_argument("--k-nearest", type=int, default=10)
@@ -126,7 +127,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from slam_amd import capi, synthetic
+    from slam_amd import capi, parallel, synthetic
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible")
@@ -145,12 +146,11 @@ def main():
                      problem["obs_mean"], problem["obs_std"], F)
     # chain seeds the way multi_mcmc draws them (successive engine outputs), global chain numbering
     all_seeds = capi.seed_sequence(args.seed + 2, C * world)
-    g.init_chains(all_seeds[rank * C:(rank + 1) * C])
+    g.init_chains(parallel.shard_seeds(all_seeds, C, rank))
     g.load_state(problem["true_rel"], problem["landmarks"])
     g.sync()
 
     summaries = torch.zeros((C, 2), dtype=torch.float64, device=dev)  # mcmcgpu_chain_summary records
-    gathered = torch.zeros((C * world, 2), dtype=torch.float64, device=dev)
     best = {"ll": float("-inf"), "chain": -1}
 
     def one_step(i):
@@ -158,13 +158,8 @@ def main():
         if args.rebuild_every and (i + 1) % args.rebuild_every == 0:
             g.rebuild()
         g.write_summaries(summaries.data_ptr())
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, summaries)
-            lls = gathered[:, 0]
-        else:
-            lls = summaries[:, 0]
-        ll, idx = torch.max(lls, dim=0)  # first maximum = lowest global chain id on ties
-        return ll, idx
+        gathered = parallel.gather_summaries(summaries, world)  # RCCL all-gather when world > 1
+        return gathered, torch.max(gathered[:, 0])  # running best log likelihood, stays on the device
 
     def barrier():
         if world > 1:
@@ -180,10 +175,16 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        ll, idx = one_step(args.warmup + i)
+        gathered, ll = one_step(args.warmup + i)
     barrier()
     elapsed = time.perf_counter() - t0
-    best["ll"], best["chain"] = float(ll), int(idx)
+    # a result is asked for: arg-max with multi_mcmc's tie rule, then the winner's state from its owner
+    best["ll"], best["chain"], owner, owner_idx = parallel.best_chain(gathered, C)
+    packed = torch.zeros(3 * T + 2 * F, dtype=torch.float64, device=dev)
+    if rank == owner:
+        g.export_state(owner_idx, packed.data_ptr())
+    parallel.broadcast_from_owner(packed, owner, world)
+    torch.cuda.synchronize(dev)
     kern_ms, launches = g.kernel_time()
     u1 = g.counters()
     s1 = g.traffic_counters()

@@ -1,5 +1,6 @@
 #!/bin/bash
-# Builds the GPU library (gfx950) and the CPU oracle used by the tests.
+# Builds the GPU library (gfx950), the C++ host program on top of its C ABI, and
+# the CPU oracle used by the tests.
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
@@ -8,4 +9,7 @@ $HIPCC -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared -std=c++17 \
 # diagnostic twin with per-phase cycle stamps (never used for reported numbers)
 $HIPCC -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared -std=c++17 -DMG_PHASE_TIMING \
   -Wall -Wno-unused-function -o slam_amd/libmcmcgpu_diag.so slam_amd/csrc/mcmcgpu.hip
+# host program: the reference's --mcmc-slam / --multi-mcmc command line over the C ABI
+g++ -O2 -std=c++17 -Wall -Wextra -ffp-contract=off -o slam_amd/host/slam_hip slam_amd/host/main.cpp \
+  -Lslam_amd -lmcmcgpu -Wl,-rpath,'$ORIGIN/..'
 make -s -C oracle

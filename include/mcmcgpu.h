@@ -99,6 +99,15 @@ int mcmcgpu_upload_problem(mcmcgpu_handle h, uint32_t T, const double* ctrl_mean
 int mcmcgpu_init_chains(mcmcgpu_handle h, uint32_t C, const uint32_t* seeds, const double* init_uniforms,
                         uint32_t n_init_uniforms);
 
+/* What mcmc_slam::set_initialiser changes for ANY initialiser (mcmc_slam.hpp:233-237,
+ * 255-259): the first n_state state edges start from state_rel[t] (= -init.get_state(t)
+ * + init.get_state(t+1)) and the first n_feat landmarks from feat_rel[f] (=
+ * -init.get_state(t_first) + init.get_feature(id)) instead of the proposals' initial
+ * values; such edges draw nothing from the chain's generator.  Call again with longer
+ * arrays as data arrives; edges beyond the arrays fall back to the defaults. */
+int mcmcgpu_set_initial_estimates(mcmcgpu_handle h, uint32_t n_state, const double* state_rel, uint32_t n_feat,
+                                  const double* feat_rel);
+
 /* The whole of slam_data::add_dataset as the sampler sees it
  * (slam_data.hpp:191-215 driving mcmc_slam::timestep, mcmc_slam.hpp:272-336,
  * and mcmc_slam::updater, :200-222): for every not yet processed timestep up

@@ -50,6 +50,7 @@ EXPORTS = [
     "mcmcgpu_destroy",
     "mcmcgpu_upload_problem",
     "mcmcgpu_init_chains",
+    "mcmcgpu_set_initial_estimates",
     "mcmcgpu_advance",
     "mcmcgpu_grow",
     "mcmcgpu_run",
@@ -172,6 +173,14 @@ class McmcGpu:
             self.lib.mcmcgpu_init_chains(self.h, ctypes.c_uint32(seeds.size), _ptr(seeds), _ptr(iu),
                                          ctypes.c_uint32(0 if iu is None else iu.size)), "mcmcgpu_init_chains")
         self.chains = int(seeds.size)
+
+    def set_initial_estimates(self, state_rel=None, feat_rel=None):
+        sr = None if state_rel is None else np.ascontiguousarray(state_rel, dtype=np.float64).reshape(-1, 3)
+        fr = None if feat_rel is None else np.ascontiguousarray(feat_rel, dtype=np.float64).reshape(-1, 2)
+        self._check(
+            self.lib.mcmcgpu_set_initial_estimates(self.h, ctypes.c_uint32(0 if sr is None else sr.shape[0]), _ptr(sr),
+                                                   ctypes.c_uint32(0 if fr is None else fr.shape[0]), _ptr(fr)),
+            "mcmcgpu_set_initial_estimates")
 
     def advance(self, upto, steps_per_timestep=0, end_steps=0):
         self._check(

@@ -58,6 +58,9 @@ struct Dev {
   const uint32_t* ffirst;     // [Fcap] timestep of a landmark's first reading
   const double* init_u;       // [n_init_u] initialiser draws per landmark, or null
   uint32_t n_init_u;
+  const double* init_rel;     // [n_init_rel][3] initial relative pose per state edge (from an initialiser)
+  const double* init_feat;    // [n_init_feat][2] initial landmark estimate relative to its first pose
+  uint32_t n_init_rel, n_init_feat;
   double usig_inv;            // 1/sigma when every reading has the same sigma, else 0
   // ---- chains --------------------------------------------------------------
   uint32_t C, NTcap;
@@ -472,7 +475,9 @@ MG_DEV void driver_add_state_edge(const Dev& d, uint32_t c, Shared& S) {
   const uint32_t t = S.Tcur;
   double mu[3], sd[3];
   load_control(d, t, mu, sd);
-  const Pose est = control_inv_observe(mu);
+  // with an initialiser its estimate is taken, else the proposal's initial value (:233-237)
+  const Pose est = t < d.n_init_rel ? Pose{d.init_rel[3 * size_t(t)], d.init_rel[3 * size_t(t) + 1], d.init_rel[3 * size_t(t) + 2]}
+                                    : control_inv_observe(mu);
   const size_t ri = size_t(c) * d.Tcap + t;
   d.relx[ri] = est.x;
   d.rely[ri] = est.y;
@@ -612,8 +617,13 @@ MG_DEV bool driver_arrival(const Dev& d, uint32_t c, Shared& S, uint32_t o) {
   const uint32_t t = S.tn;
   const double mu = rec.mu, sd = d.osd[o];
   if (o == d.foff[f]) {  // first reading of this landmark: add_feature_edge, :248-270
-    const double u = (d.init_u && f < d.n_init_u) ? d.init_u[f] : rng_uniform(S.rng);
-    const Vec2 est = polar(mu, u * 2 * kPi);
+    Vec2 est;
+    if (f < d.n_init_feat) {  // an initialiser's estimate (:255-258): no draw from the chain
+      est = Vec2{d.init_feat[2 * size_t(f)], d.init_feat[2 * size_t(f) + 1]};
+    } else {
+      const double u = (d.init_u && f < d.n_init_u) ? d.init_u[f] : rng_uniform(S.rng);
+      est = polar(mu, u * 2 * kPi);
+    }
     d.fex[fi] = est.x;
     d.fey[fi] = est.y;
     d.fpar[fi] = 0;

@@ -164,6 +164,8 @@ int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out) {
   ALLOC(d.tobs, d.Ncap);
   ALLOC(d.ffirst, d.Fcap);
   ALLOC(d.init_u, d.Fcap);
+  ALLOC(d.init_rel, 3 * size_t(d.Tcap));
+  ALLOC(d.init_feat, 2 * size_t(d.Fcap));
   ALLOC(d.relx, C * d.Tcap);
   ALLOC(d.rely, C * d.Tcap);
   ALLOC(d.relth, C * d.Tcap);
@@ -317,6 +319,8 @@ int mcmcgpu_init_chains(mcmcgpu_handle h, uint32_t C, const uint32_t* seeds, con
   uint32_t* dseeds = h->seed_stage;
   HIP_TRY(h, hipMemcpyAsync(dseeds, seeds, size_t(C) * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
   d.n_init_u = 0;
+  d.n_init_rel = 0;
+  d.n_init_feat = 0;
   if (init_uniforms && n_init_uniforms) {
     HIP_TRY(h, hipMemcpyAsync(const_cast<double*>(d.init_u), init_uniforms, size_t(n_init_uniforms) * sizeof(double),
                               hipMemcpyHostToDevice, h->stream));
@@ -325,6 +329,24 @@ int mcmcgpu_init_chains(mcmcgpu_handle h, uint32_t C, const uint32_t* seeds, con
   hipLaunchKernelGGL(init_chains_kernel, dim3((C + 255) / 256), dim3(256), 0, h->stream, d, dseeds);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int mcmcgpu_set_initial_estimates(mcmcgpu_handle h, uint32_t n_state, const double* state_rel, uint32_t n_feat,
+                                   const double* feat_rel) {
+  if (!h) return MCMCGPU_ERR_ARGUMENT;
+  if ((n_state && !state_rel) || (n_feat && !feat_rel)) return fail(h, MCMCGPU_ERR_ARGUMENT, "null argument");
+  if (n_state > h->d.Tcap || n_feat > h->d.Fcap) return fail(h, MCMCGPU_ERR_CAPACITY, "more estimates than capacity");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  if (n_state)
+    HIP_TRY(h, hipMemcpyAsync(const_cast<double*>(h->d.init_rel), state_rel, sizeof(double) * 3 * n_state,
+                              hipMemcpyHostToDevice, h->stream));
+  if (n_feat)
+    HIP_TRY(h, hipMemcpyAsync(const_cast<double*>(h->d.init_feat), feat_rel, sizeof(double) * 2 * n_feat,
+                              hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->d.n_init_rel = n_state;
+  h->d.n_init_feat = n_feat;
   return 0;
 }
 

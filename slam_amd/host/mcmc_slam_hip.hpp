@@ -1,0 +1,365 @@
+// GPU-backed drop-in for the reference's sampler classes.
+//
+// slam::mcmc_slam<ControlModel, ObservationModel> here has the public surface
+// of the reference class of the same name (src/slam/mcmc_slam.hpp:37-223):
+// constructor (shared_ptr<const slam_data>, seed), non-copyable,
+// get_log_likelihood(), set_initialiser(), update(), the timestep_listener and
+// slam_result members, and the nested `updater`.  Its private state -- relative
+// poses, landmark estimates, both weight trees, the log likelihood and the
+// random stream -- lives on the GPU behind an mcmcgpu handle
+// (include/mcmcgpu.h); nothing of the sampler runs on the host.
+//
+// slam::multi_mcmc mirrors src/slam/multi_mcmc.hpp:34-169: C chains in ONE
+// handle (one workgroup each), seeded by successive draws of one generator,
+// stepped together, best chain = first maximum of the log likelihoods.
+//
+// The class only uses these members of its collaborators, so it compiles
+// against slam_types.hpp / slam_data.hpp here and against the reference's own
+// headers alike: data->current_timestep(), control(t).mean()(i) / stddev()(i),
+// observations() / observations_at(t) [positions], observation_info::id() /
+// index() / observation().mean()(0) / stddev()(0), slam_result::get_state /
+// get_feature, pose::cartesian / x() / y() / bearing(), position::cartesian /
+// x() / y(), bitree::push_back / clear.
+#ifndef SLAM_AMD_HOST_MCMC_SLAM_HIP_HPP
+#define SLAM_AMD_HOST_MCMC_SLAM_HIP_HPP
+
+#include <cstdint>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/mcmcgpu.h"
+#include "slam_data.hpp"
+#include "slam_types.hpp"
+
+namespace slam {
+
+// Capacities of the device buffers a sampler allocates at construction
+// (nothing is allocated later).  The defaults hold a million-pose run of one
+// chain in well under a gigabyte.
+struct gpu_capacity {
+  std::uint32_t timesteps = 1u << 20, features = 1u << 12, observations = 1u << 22;
+  int device = 0;
+  bool feature_uniform_first = true;  // draw order inside a landmark proposal, see mcmcgpu_config
+};
+
+namespace detail {
+
+inline void check(mcmcgpu_handle h, int rc, const char* what) {
+  if (rc != 0) throw std::runtime_error(std::string(what) + ": " + mcmcgpu_last_error(h));
+}
+
+// The flattened, growing copy of slam_data that is uploaded to the device:
+// controls and readings in arrival order, landmarks numbered by first
+// appearance (the index into the reference's feature_estimates vector).
+template <class ControlModel, class ObservationModel>
+class device_problem {
+  using data_type = slam_data<ControlModel, ObservationModel>;
+  std::vector<double> cmean, cstd, omean, ostd;
+  std::vector<std::uint32_t> ot, of;
+  std::map<std::size_t, std::uint32_t> dense;
+  std::vector<std::size_t> ids;  // dense index -> landmark id
+
+ public:
+  std::uint32_t T() const { return std::uint32_t(cmean.size() / 3); }
+  std::uint32_t N() const { return std::uint32_t(ot.size()); }
+  std::uint32_t F() const { return std::uint32_t(ids.size()); }
+  const std::vector<std::size_t>& feature_ids() const { return ids; }
+  const std::map<std::size_t, std::uint32_t>& feature_index() const { return dense; }
+
+  // Takes over everything `data` holds up to timestep `upto` that is not here yet.
+  // Returns the dense indices of landmarks met for the first time, with their timestep.
+  std::vector<std::pair<std::uint32_t, std::size_t>> absorb(const data_type& data, std::size_t upto) {
+    std::vector<std::pair<std::uint32_t, std::size_t>> fresh;
+    while (T() < upto) {
+      const ControlModel& c = data.control(timestep_type(T()));
+      for (int i = 0; i < 3; ++i) cmean.push_back(c.mean()(i));
+      for (int i = 0; i < 3; ++i) cstd.push_back(c.stddev()(i));
+    }
+    const auto& all = data.observations();
+    for (std::size_t i = N(); i < all.size() && std::size_t(all[i].first) <= upto; ++i) {
+      const auto& info = all[i].second;
+      const std::size_t id = info.id();
+      auto ins = dense.emplace(id, std::uint32_t(ids.size()));
+      if (ins.second) {
+        ids.push_back(id);
+        fresh.emplace_back(ins.first->second, std::size_t(all[i].first));
+      }
+      ot.push_back(std::uint32_t(std::size_t(all[i].first)));
+      of.push_back(ins.first->second);
+      omean.push_back(info.observation().mean()(0));
+      ostd.push_back(info.observation().stddev()(0));
+    }
+    return fresh;
+  }
+  void upload(mcmcgpu_handle h) const {
+    check(h, mcmcgpu_upload_problem(h, T(), cmean.data(), cstd.data(), N(), ot.data(), of.data(), omean.data(),
+                                    ostd.data(), F()),
+          "mcmcgpu_upload_problem");
+  }
+};
+
+}  // namespace detail
+
+template <class ControlModel, class ObservationModel>
+class mcmc_slam : public slam_result_of<ControlModel, ObservationModel> {
+  using slam_result_type = slam_result_of<ControlModel, ObservationModel>;
+  using slam_data_type = slam_data<ControlModel, ObservationModel>;
+  using state_type = typename slam_result_type::state_type;
+  using feature_type = typename slam_result_type::feature_type;
+  using trajectory_type = typename slam_result_type::trajectory_type;
+  using feature_map_type = typename slam_result_type::feature_map_type;
+
+  const std::shared_ptr<const slam_data_type> data;
+  std::shared_ptr<slam_result_type> initialiser;
+  mcmcgpu_handle h = nullptr;
+  detail::device_problem<ControlModel, ObservationModel> problem;
+  std::vector<double> init_rel, init_feat;  // what the initialiser says about new edges
+  std::size_t next_timestep = 0;
+  std::uint64_t accepts_seen = 0;
+
+  // host mirrors for the slam_result read interface, rebuilt on demand
+  mutable trajectory_type trajectory_mirror;
+  mutable feature_map_type map_mirror;
+  mutable bool trajectory_valid = false, map_valid = false;
+
+  void invalidate() { trajectory_valid = map_valid = false; }
+
+ public:
+  mcmc_slam(const decltype(data)& data, unsigned int seed, const gpu_capacity& cap = gpu_capacity()) : data(data) {
+    mcmcgpu_config cfg{};
+    cfg.device = cap.device;
+    cfg.max_chains = 1;
+    cfg.max_timesteps = cap.timesteps;
+    cfg.max_features = cap.features;
+    cfg.max_observations = cap.observations;
+    cfg.feature_uniform_first = cap.feature_uniform_first ? 1 : 0;
+    if (mcmcgpu_create(&cfg, &h) != 0) throw std::runtime_error(std::string("mcmcgpu_create: ") + mcmcgpu_last_error(nullptr));
+    const std::uint32_t s = seed;
+    detail::check(h, mcmcgpu_init_chains(h, 1, &s, nullptr, 0), "mcmcgpu_init_chains");
+  }
+  ~mcmc_slam() { mcmcgpu_destroy(h); }
+  mcmc_slam(const mcmc_slam&) = delete;
+  mcmc_slam& operator=(const mcmc_slam&) = delete;
+
+  double get_log_likelihood() const {
+    double ll = 0;
+    detail::check(h, mcmcgpu_get_log_likelihood(h, &ll), "mcmcgpu_get_log_likelihood");
+    return ll;
+  }
+
+  void set_initialiser(const decltype(initialiser)& init) { initialiser = init; }
+
+  // One Metropolis-Hastings step; true if the proposal was accepted.
+  bool update() { return update(1) == 1; }
+
+  // `count` steps in one launch; returns how many were accepted.
+  unsigned int update(unsigned int count) {
+    if (next_timestep == 0 || count == 0) return 0;
+    detail::check(h, mcmcgpu_run(h, count), "mcmcgpu_run");
+    std::uint64_t acc = 0;
+    detail::check(h, mcmcgpu_get_counters(h, nullptr, &acc, nullptr), "mcmcgpu_get_counters");
+    detail::check(h, mcmcgpu_sync(h), "mcmcgpu_sync");
+    const unsigned int n = static_cast<unsigned int>(acc - accepts_seen);
+    accepts_seen = acc;
+    if (n) invalidate();
+    return n;
+  }
+
+  // timestep_listener: grow the graph up to timestep t with what `data` holds.
+  void timestep(timestep_type t) override {
+    if (std::size_t(t) + 1 <= next_timestep) return;
+    const auto fresh = problem.absorb(*data, std::size_t(t));
+    if (initialiser) {
+      // -init(t) + init(t+1) per new state edge, -init(t_first) + init(landmark) per new landmark
+      for (std::size_t e = init_rel.size() / 3; e < problem.T(); ++e) {
+        const state_type d = -initialiser->get_state(timestep_type(e)) + initialiser->get_state(timestep_type(e + 1));
+        init_rel.insert(init_rel.end(), {d.x(), d.y(), d.bearing()});
+      }
+      for (const auto& f : fresh) {
+        const feature_type p =
+            -initialiser->get_state(timestep_type(f.second)) + initialiser->get_feature(featureid_type(problem.feature_ids()[f.first]));
+        init_feat.insert(init_feat.end(), {p.x(), p.y()});
+      }
+      detail::check(h,
+                    mcmcgpu_set_initial_estimates(h, std::uint32_t(init_rel.size() / 3), init_rel.data(),
+                                                  std::uint32_t(init_feat.size() / 2), init_feat.data()),
+                    "mcmcgpu_set_initial_estimates");
+    }
+    problem.upload(h);
+    detail::check(h, mcmcgpu_grow(h, std::uint32_t(std::size_t(t))), "mcmcgpu_grow");
+    next_timestep = std::size_t(t) + 1;
+    invalidate();
+  }
+
+  timestep_type current_timestep() const override { return timestep_type(next_timestep == 0 ? 0 : next_timestep - 1); }
+
+  feature_type get_feature(featureid_type id) const override { return get_feature_map().at(id); }
+
+  // Relative poses as a bitree, like the reference returns them.
+  const trajectory_type& get_trajectory() const override {
+    if (!trajectory_valid) {
+      const std::size_t T = current_timestep();
+      std::vector<double> rel(3 * T);
+      detail::check(h, mcmcgpu_get_state(h, 0, rel.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr),
+                    "mcmcgpu_get_state");
+      trajectory_mirror.clear();
+      trajectory_mirror.reserve(T);
+      for (std::size_t t = 0; t < T; ++t)
+        trajectory_mirror.push_back(state_type::cartesian(rel[3 * t], rel[3 * t + 1], rel[3 * t + 2]));
+      trajectory_valid = true;
+    }
+    return trajectory_mirror;
+  }
+
+  const feature_map_type& get_feature_map() const override {
+    if (!map_valid) {
+      std::uint32_t T = 0, F = 0, C = 0;
+      detail::check(h, mcmcgpu_get_dims(h, &T, &F, &C), "mcmcgpu_get_dims");
+      std::vector<double> world(2 * std::size_t(F));
+      detail::check(h, mcmcgpu_get_state(h, 0, nullptr, nullptr, nullptr, nullptr, world.data(), nullptr, nullptr),
+                    "mcmcgpu_get_state");
+      map_mirror.clear();
+      for (std::uint32_t f = 0; f < F; ++f)
+        map_mirror[problem.feature_ids()[f]] = feature_type::cartesian(world[2 * f], world[2 * f + 1]);
+      map_valid = true;
+    }
+    return map_mirror;
+  }
+
+  mcmcgpu_handle native_handle() const { return h; }
+
+  class updater : public timestep_listener {
+    std::shared_ptr<mcmc_slam> instance;
+    unsigned int steps, end_steps;
+
+   public:
+    updater(const decltype(instance)& instance, unsigned int steps = 0, unsigned int end_steps = 0)
+        : instance(instance), steps(steps), end_steps(end_steps) {}
+    void timestep(timestep_type t) override {
+      instance->timestep(t);
+      instance->update(steps);
+    }
+    void completed() override {
+      instance->completed();
+      instance->update(end_steps);
+    }
+  };
+};
+
+template <class ControlModel, class ObservationModel>
+class multi_mcmc : public slam_result_of<ControlModel, ObservationModel> {
+  using slam_result_type = slam_result_of<ControlModel, ObservationModel>;
+  using slam_data_type = slam_data<ControlModel, ObservationModel>;
+  using state_type = typename slam_result_type::state_type;
+  using feature_type = typename slam_result_type::feature_type;
+  using trajectory_type = typename slam_result_type::trajectory_type;
+  using feature_map_type = typename slam_result_type::feature_map_type;
+
+  const std::shared_ptr<const slam_data_type> data;
+  mcmcgpu_handle h = nullptr;
+  detail::device_problem<ControlModel, ObservationModel> problem;
+  unsigned int chains, mcmc_end_steps;
+  std::size_t next_timestep = 0;
+  unsigned int max_likelihood = 0;  // index of the best chain
+  double best_ll = 0;
+  std::string report_path;
+  mutable trajectory_type trajectory_mirror;
+  mutable feature_map_type map_mirror;
+
+ public:
+  multi_mcmc(std::shared_ptr<const slam_data_type> data, unsigned int num_chains, unsigned int end_steps,
+             unsigned int seed, const gpu_capacity& cap = gpu_capacity(),
+             const std::string& report = "multi-mcmc-report.txt")
+      : data(data), chains(num_chains), mcmc_end_steps(end_steps), report_path(report) {
+    mcmcgpu_config cfg{};
+    cfg.device = cap.device;
+    cfg.max_chains = num_chains;
+    cfg.max_timesteps = cap.timesteps;
+    cfg.max_features = cap.features;
+    cfg.max_observations = cap.observations;
+    cfg.feature_uniform_first = cap.feature_uniform_first ? 1 : 0;
+    if (mcmcgpu_create(&cfg, &h) != 0) throw std::runtime_error(std::string("mcmcgpu_create: ") + mcmcgpu_last_error(nullptr));
+    std::vector<std::uint32_t> seeds(num_chains);
+    mcmcgpu_seed_sequence(seed, num_chains, seeds.data());  // successive draws of random_source(seed)
+    detail::check(h, mcmcgpu_init_chains(h, num_chains, seeds.data(), nullptr, 0), "mcmcgpu_init_chains");
+  }
+  ~multi_mcmc() { mcmcgpu_destroy(h); }
+  multi_mcmc(const multi_mcmc&) = delete;
+  multi_mcmc& operator=(const multi_mcmc&) = delete;
+
+  unsigned int num_chains() const { return chains; }
+  double get_log_likelihood() const { return best_ll; }
+
+  // `count` updates on every chain, then the arg-max (strict >, first maximum wins).
+  void update(unsigned int count) {
+    detail::check(h, mcmcgpu_run(h, count), "mcmcgpu_run");
+    std::vector<double> ll(chains);
+    detail::check(h, mcmcgpu_get_log_likelihood(h, ll.data()), "mcmcgpu_get_log_likelihood");
+    for (unsigned int c = 0; c < chains; ++c)
+      if (ll[c] > ll[max_likelihood]) max_likelihood = c;
+    best_ll = ll[max_likelihood];
+  }
+
+  void timestep(timestep_type t) override {
+    if (std::size_t(t) + 1 <= next_timestep) return;
+    problem.absorb(*data, std::size_t(t));
+    problem.upload(h);
+    detail::check(h, mcmcgpu_grow(h, std::uint32_t(std::size_t(t))), "mcmcgpu_grow");
+    next_timestep = std::size_t(t) + 1;
+  }
+
+  // End steps in report intervals of 100, one report line each.
+  void completed() override {
+    std::ofstream report(report_path);
+    unsigned int remaining = mcmc_end_steps;
+    const unsigned int report_every = 100;
+    while (remaining > 0) {
+      const unsigned int n = remaining > report_every ? report_every : remaining;
+      update(n);
+      remaining -= n;
+      std::vector<std::uint64_t> upd(chains), acc(chains);
+      detail::check(h, mcmcgpu_get_counters(h, upd.data(), acc.data(), nullptr), "mcmcgpu_get_counters");
+      std::uint64_t u = 0, a = 0;
+      for (unsigned int c = 0; c < chains; ++c) {
+        u += upd[c];
+        a += acc[c];
+      }
+      report << (double(u) / chains) << '\t' << (double(a) / chains) << '\t' << get_log_likelihood() << '\n';
+    }
+  }
+
+  timestep_type current_timestep() const override { return timestep_type(next_timestep == 0 ? 0 : next_timestep - 1); }
+
+  const trajectory_type& get_trajectory() const override {
+    const std::size_t T = current_timestep();
+    std::vector<double> rel(3 * T);
+    detail::check(h, mcmcgpu_get_state(h, max_likelihood, rel.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr),
+                  "mcmcgpu_get_state");
+    trajectory_mirror.clear();
+    for (std::size_t t = 0; t < T; ++t)
+      trajectory_mirror.push_back(state_type::cartesian(rel[3 * t], rel[3 * t + 1], rel[3 * t + 2]));
+    return trajectory_mirror;
+  }
+
+  const feature_map_type& get_feature_map() const override {
+    std::uint32_t T = 0, F = 0, C = 0;
+    detail::check(h, mcmcgpu_get_dims(h, &T, &F, &C), "mcmcgpu_get_dims");
+    std::vector<double> world(2 * std::size_t(F));
+    detail::check(h, mcmcgpu_get_state(h, max_likelihood, nullptr, nullptr, nullptr, nullptr, world.data(), nullptr, nullptr),
+                  "mcmcgpu_get_state");
+    map_mirror.clear();
+    for (std::uint32_t f = 0; f < F; ++f)
+      map_mirror[problem.feature_ids()[f]] = feature_type::cartesian(world[2 * f], world[2 * f + 1]);
+    return map_mirror;
+  }
+
+  mcmcgpu_handle native_handle() const { return h; }
+};
+
+}  // namespace slam
+
+#endif  // SLAM_AMD_HOST_MCMC_SLAM_HIP_HPP

@@ -1,0 +1,261 @@
+// Host-side data model around the sampler, with the reference's names and call
+// sequence: the observer bus (slam_data), the raw dataset, the Plaza range-only
+// text loader and the dead-reckoning initialiser.  Stand-alone (std only).
+//
+// Reference counterparts (paths relative to the reference tree):
+//   slam::slam_data        src/slam/slam_data.hpp:28-215
+//   slam::dataset_impl     src/slam/dataset_impl.hpp:20-85
+//   read_range_only_data   src/dataset.cpp:17-112
+//   slam::slam_initialiser src/slam/slam_initialiser.hpp:21-50
+#ifndef SLAM_AMD_HOST_SLAM_DATA_HPP
+#define SLAM_AMD_HOST_SLAM_DATA_HPP
+
+#include <algorithm>
+#include <cstdint>
+#include <fstream>
+#include <memory>
+#include <set>
+#include <stdexcept>
+#include <string>
+#include <utility>
+
+#include "../../include/mcmcgpu.h"
+#include "slam_types.hpp"
+
+namespace slam {
+
+// Readings and controls as probability models, in arrival order, plus the
+// listeners that are told about every new piece of data.
+template <class ControlModel, class ObservationModel>
+class slam_data : public data_source {
+ public:
+  using feature_observations = std::vector<std::pair<timestep_type, ObservationModel>>;  // time-sorted
+
+  class observation_info {
+    const slam_data* owner;
+    std::size_t fid, i;
+
+   public:
+    observation_info(const slam_data* o, std::size_t id, std::size_t index) : owner(o), fid(id), i(index) {}
+    featureid_type id() const { return featureid_type(fid); }
+    std::size_t index() const { return i; }
+    const ObservationModel& observation() const { return owner->m_features.at(fid)[i].second; }
+  };
+
+  struct listener : public virtual timestep_listener {
+    virtual void control(timestep_type, const ControlModel&) = 0;
+    virtual void observation(timestep_type, const observation_info&) = 0;
+  };
+
+  using observation_collection = std::vector<std::pair<timestep_type, observation_info>>;
+
+ private:
+  std::map<std::size_t, feature_observations> m_features;
+  observation_collection m_observations;
+  std::vector<ControlModel> m_controls;
+  std::vector<std::weak_ptr<timestep_listener>> m_timestep_listeners;
+  std::vector<std::weak_ptr<listener>> m_listeners;
+
+ public:
+  timestep_type current_timestep() const override { return timestep_type(m_controls.size()); }
+  void timestep(timestep_type t) override {
+    for (auto& w : m_timestep_listeners)
+      if (auto l = w.lock()) l->timestep(t);
+  }
+  void completed() override {
+    for (auto& w : m_timestep_listeners)
+      if (auto l = w.lock()) l->completed();
+  }
+  const ControlModel& control(timestep_type t) const { return m_controls.at(t); }
+  const observation_collection& observations() const { return m_observations; }
+  // [first, last) positions in observations() of the readings taken at timestep t
+  std::pair<std::size_t, std::size_t> observations_at(timestep_type t) const {
+    auto lo = std::lower_bound(m_observations.begin(), m_observations.end(), std::size_t(t),
+                               [](const auto& o, std::size_t v) { return std::size_t(o.first) < v; });
+    auto hi = std::upper_bound(m_observations.begin(), m_observations.end(), std::size_t(t),
+                               [](std::size_t v, const auto& o) { return v < std::size_t(o.first); });
+    return {std::size_t(lo - m_observations.begin()), std::size_t(hi - m_observations.begin())};
+  }
+  bool feature_observed(featureid_type f) const { return m_features.count(f) != 0; }
+  const feature_observations& get_observations(featureid_type f) const { return m_features.at(f); }
+
+  void add_control(const ControlModel& c) {
+    const timestep_type t = current_timestep();
+    m_controls.push_back(c);
+    for (auto& w : m_listeners)
+      if (auto l = w.lock()) l->control(t, m_controls.back());
+  }
+  void add_observation(featureid_type id, const ObservationModel& obs) {
+    const timestep_type t = current_timestep();
+    auto& list = m_features[id];
+    list.emplace_back(t, obs);
+    m_observations.emplace_back(t, observation_info(this, id, list.size() - 1));
+    for (auto& w : m_listeners)
+      if (auto l = w.lock()) l->observation(t, m_observations.back().second);
+  }
+  void add_timestep_listener(const std::shared_ptr<timestep_listener>& l) { m_timestep_listeners.push_back(l); }
+  void add_listener(const std::shared_ptr<listener>& l) {
+    add_timestep_listener(l);
+    m_listeners.push_back(l);
+  }
+
+  // Replays a dataset in the reference's order: readings of a timestep, then the
+  // timestep signal, then the next control (slam_data.hpp:191-215).
+  template <class Dataset>
+  void add_dataset(const Dataset& data, const typename ControlModel::builder& cb,
+                   const typename ObservationModel::builder& ob) {
+    auto add_observations = [&](timestep_type t) {
+      const auto r = data.observations_at(t);
+      for (std::size_t i = r.first; i < r.second; ++i)
+        add_observation(data.observations()[i].second.id, ob(data.observations()[i].second.observation));
+    };
+    add_observations(current_timestep());
+    timestep(current_timestep());
+    while (current_timestep() < data.current_timestep()) {
+      const timestep_type t = current_timestep();
+      add_control(cb(data.control(t), data.timedelta(t)));
+      add_observations(current_timestep());
+      timestep(current_timestep());
+    }
+    completed();
+  }
+};
+
+// Raw controls (v, w, slip rate), time deltas and range readings of a run.
+template <class ControlModel, class ObservationModel>
+class dataset_impl {
+ public:
+  using control_type = typename ControlModel::vector_type;
+  using observation_type = typename ObservationModel::vector_type;
+  struct observation_info {
+    featureid_type id;
+    observation_type observation;
+  };
+  using observation_collection = std::vector<std::pair<timestep_type, observation_info>>;
+
+ private:
+  std::vector<control_type> m_controls;
+  utility::bitree<double> m_timedeltas;
+  observation_collection m_observations;
+
+ public:
+  timestep_type current_timestep() const { return timestep_type(m_controls.size()); }
+  const control_type& control(timestep_type t) const { return m_controls.at(t); }
+  double timedelta(timestep_type t) const { return m_timedeltas[t]; }
+  double timestamp(timestep_type t) const { return m_timedeltas.accumulate(t); }
+  timestep_type timestep_at(double timestamp) const { return timestep_type(m_timedeltas.binary_search(timestamp)); }
+  const observation_collection& observations() const { return m_observations; }
+  std::pair<std::size_t, std::size_t> observations_at(timestep_type t) const {
+    auto lo = std::lower_bound(m_observations.begin(), m_observations.end(), std::size_t(t),
+                               [](const auto& o, std::size_t v) { return std::size_t(o.first) < v; });
+    auto hi = std::upper_bound(m_observations.begin(), m_observations.end(), std::size_t(t),
+                               [](std::size_t v, const auto& o) { return v < std::size_t(o.first); });
+    return {std::size_t(lo - m_observations.begin()), std::size_t(hi - m_observations.begin())};
+  }
+  void add_control(double dt, const control_type& c) {
+    m_timedeltas.push_back(dt);
+    m_controls.push_back(c);
+  }
+  // keeps the collection sorted by timestep; equal timesteps stay in insertion order
+  void add_observation(timestep_type t, featureid_type id, observation_type obs) {
+    auto at = std::upper_bound(m_observations.begin(), m_observations.end(), std::size_t(t),
+                               [](std::size_t v, const auto& o) { return v < std::size_t(o.first); });
+    m_observations.insert(at, std::make_pair(t, observation_info{id, obs}));
+  }
+};
+
+using range_only_dataset = dataset_impl<planar_robot::velocity_slip_model, planar_robot::range_only_model>;
+
+// CMU Plaza range-only logs: <name>_GT.txt (time x y heading; the first row gives
+// the start time), <name>_DR.txt (time, distance and heading increments; control
+// = increment / dt, third component 0), <name>_TD.txt (time antenna beacon
+// range; the timestep is found from the time since start, the first reading per
+// (timestep, beacon) wins).  The reference's loader also reads the beacon
+// survey and the GPS track as ground truth and writes a controls.txt into the
+// data directory; neither is part of the sampler's input and both are left out.
+inline std::shared_ptr<range_only_dataset> read_range_only_data(const std::string& dir, const std::string& name) {
+  auto open = [&](const char* suffix) {
+    const std::string path = dir + "/" + name + "/" + name + suffix;
+    std::ifstream f(path);
+    if (!f) throw std::runtime_error("cannot open " + path);
+    return f;
+  };
+  auto out = std::make_shared<range_only_dataset>();
+  double start;
+  {
+    auto gt = open("_GT.txt");
+    double x, y, b;
+    if (!(gt >> start >> x >> y >> b)) throw std::runtime_error(name + "_GT.txt is empty");
+  }
+  {
+    auto dr = open("_DR.txt");
+    double stamp, prev = start;
+    range_only_dataset::control_type c;
+    while (dr >> stamp >> c(0) >> c(1)) {
+      const double dt = stamp - prev;
+      prev = stamp;
+      range_only_dataset::control_type u;
+      for (int i = 0; i < 3; ++i) u(i) = c(i) / dt;
+      out->add_control(dt, u);
+    }
+  }
+  {
+    auto td = open("_TD.txt");
+    double stamp, antenna, id;
+    range_only_dataset::observation_type r;
+    std::set<std::pair<std::size_t, std::size_t>> seen;
+    while (td >> stamp >> antenna >> id >> r(0)) {
+      const featureid_type fid(std::size_t(std::round(id)));
+      const timestep_type t = out->timestep_at(stamp - start);
+      if (seen.emplace(std::size_t(t), std::size_t(fid)).second) out->add_observation(t, fid, r);
+    }
+  }
+  return out;
+}
+
+// Dead reckoning plus a first guess for every new landmark: the estimate a
+// sampler with an initialiser starts every new edge from.  Draws one uniform
+// per new landmark from its own generator (the library's host generator is
+// the reference's random_source: mcmcgpu_uniform_sequence).
+template <class ControlModel, class ObservationModel>
+class slam_initialiser : public slam_data<ControlModel, ObservationModel>::listener,
+                         public slam_result_of<ControlModel, ObservationModel> {
+  using data_type = slam_data<ControlModel, ObservationModel>;
+  using result_type = slam_result_of<ControlModel, ObservationModel>;
+  unsigned int m_seed;
+  std::uint32_t m_draws = 0;
+  typename result_type::trajectory_type m_trajectory;
+  typename result_type::feature_map_type m_map;
+
+  double next_uniform() {  // draw number m_draws of random_source(seed).uniform()
+    std::vector<double> u(m_draws + 1);
+    mcmcgpu_uniform_sequence(m_seed, m_draws + 1, u.data());
+    return u[m_draws++];
+  }
+
+ public:
+  explicit slam_initialiser(unsigned int seed) : m_seed(seed) {}
+  unsigned int seed() const { return m_seed; }
+  void timestep(timestep_type) override {}
+  void control(timestep_type, const ControlModel& c) override {
+    // inv_observe of the control mean (velocity_model.hpp:51-63, :150-152)
+    const double s = c.mean()(0), alpha = c.mean()(1), beta = c.mean()(2), r = s / alpha;
+    m_trajectory.push_back(std::isfinite(r)
+                               ? planar_robot::pose::cartesian(r * std::sin(alpha), r - r * std::cos(alpha), alpha + beta)
+                               : planar_robot::pose::cartesian(s, 0.0, beta));
+  }
+  void observation(timestep_type t, const typename data_type::observation_info& o) override {
+    if (o.index() == 0) {
+      const double pi = 3.14159265358979323846;
+      m_map[o.id()] = this->get_state(t) +
+                      planar_robot::position::polar(o.observation().mean()(0), next_uniform() * 2 * pi);
+    }
+  }
+  timestep_type current_timestep() const override { return timestep_type(m_trajectory.size()); }
+  const typename result_type::trajectory_type& get_trajectory() const override { return m_trajectory; }
+  const typename result_type::feature_map_type& get_feature_map() const override { return m_map; }
+};
+
+}  // namespace slam
+
+#endif  // SLAM_AMD_HOST_SLAM_DATA_HPP

@@ -1,0 +1,57 @@
+"""Multi-GPU layer: chains are sharded over ranks (one process per GPU), nothing
+else is.  The only exchange is what the reference's multi_mcmc does serially
+(src/slam/multi_mcmc.hpp:105-139): per-chain summaries are all-gathered every
+report interval, the best chain is the arg-max of the log likelihoods (the FIRST
+maximum in global chain order, matching the strict `>` at :115), and its state
+is broadcast from its owner only when a result is asked for.
+
+Works on any torch.distributed backend: "nccl" (= RCCL over xGMI) on GPUs,
+"gloo" in the CPU tests.  With a world size of 1 no collective is issued.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_range(chains_per_rank, rank):
+    """Global chain ids owned by `rank`: a contiguous block, GPU g owns [g*C, (g+1)*C)."""
+    return rank * chains_per_rank, (rank + 1) * chains_per_rank
+
+
+def shard_seeds(all_seeds, chains_per_rank, rank):
+    """multi_mcmc draws one seed per chain from a single generator, in chain order
+    (multi_mcmc.hpp:160-166); every rank takes its block of that one sequence."""
+    lo, hi = shard_range(chains_per_rank, rank)
+    return np.ascontiguousarray(all_seeds[lo:hi])
+
+
+def gather_summaries(local, world, group=None):
+    """local: [C, 2] float64 tensor of mcmcgpu_chain_summary records (column 0 = log
+    likelihood).  Returns the [world*C, 2] tensor of all ranks, in global chain order."""
+    if world == 1:
+        return local
+    out = torch.empty((local.shape[0] * world, local.shape[1]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+    return out
+
+
+def best_chain(all_summaries, chains_per_rank):
+    """(log likelihood, global chain id, owner rank, index on the owner) of the best chain;
+    ties go to the lowest global chain id."""
+    lls = all_summaries[:, 0]
+    best = torch.max(lls)
+    gid = int(torch.nonzero(lls == best)[0].item())
+    return float(best), gid, gid // chains_per_rank, gid % chains_per_rank
+
+
+def broadcast_from_owner(buf, owner, world, group=None):
+    """Broadcast of the winner's packed state (relative poses + landmark estimates)."""
+    if world > 1:
+        dist.broadcast(buf, src=owner, group=group)
+    return buf
+
+
+def counts_of(all_summaries):
+    """(updates, accepts) per chain, decoded from the second 8 bytes of each record."""
+    raw = all_summaries[:, 1].contiguous().cpu().numpy().view(np.uint32).reshape(-1, 2)
+    return raw[:, 0].copy(), raw[:, 1].copy()

@@ -1,0 +1,71 @@
+"""The C++ host program (slam_amd/host): the reference's command line over the C ABI.
+CPU: its Plaza loader against the golden loader facts.  GPU: Plaza2 end to end
+through the drop-in classes against the golden run of the oracle."""
+import json
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "slam_amd", "host", "slam_hip")
+PLAZA = os.path.join(ROOT, "tests", "golden", "plaza")
+
+
+def golden(name):
+    with open(os.path.join(ROOT, "tests", "golden", f"{name.lower()}_mcmc_slam.json")) as f:
+        return json.load(f)
+
+
+def run(*args, timeout=600):
+    out = subprocess.run([EXE, *args], capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stdout + out.stderr
+    return out.stdout
+
+
+@pytest.mark.parametrize("name", ["Plaza1", "Plaza2"])
+def test_loader_matches_golden_facts(name):
+    """Same timesteps, same de-duplicated readings, same control models as the oracle's loader, bit for bit."""
+    g = golden(name)["loader"]
+    lines = run("--dataset", name, "--dataset-dir", PLAZA, "--sensor-range-stddev", "1", "--dump-loader").splitlines()
+    kv = {ln.split()[0]: ln.split()[1:] for ln in lines if not ln.startswith("obs")}
+    assert int(kv["T"][0]) == g["T"] and int(kv["N"][0]) == g["N"]
+    obs = {int(ln.split()[1]): ln.split()[2:] for ln in lines if ln.startswith("obs")}
+    for i, (t, fid, mu) in enumerate(g["first"]):
+        assert (int(obs[i][0]), int(obs[i][1]), float.fromhex(obs[i][2])) == (t, fid, float.fromhex(mu))
+    for j, (t, fid, mu) in enumerate(g["last"]):
+        i = g["N"] - 5 + j
+        assert (int(obs[i][0]), int(obs[i][1]), float.fromhex(obs[i][2])) == (t, fid, float.fromhex(mu))
+    assert [float.fromhex(v) for v in kv["sum_ctrl_mean"]] == [float.fromhex(v) for v in g["sum_ctrl_mean"]]
+    assert [float.fromhex(v) for v in kv["sum_ctrl_std"]] == [float.fromhex(v) for v in g["sum_ctrl_std"]]
+
+
+def test_unknown_option_is_an_error():
+    out = subprocess.run([EXE, "--dataset", "Plaza2", "--no-such-flag"], capture_output=True, text=True)
+    assert out.returncode == 1 and "unknown option" in out.stderr
+
+
+@pytest.mark.gpu
+def test_plaza2_through_the_drop_in_classes():
+    """--mcmc-slam with the dead-reckoning initialiser, event by event through slam_data, 10 updates per
+    timestep and 1000 at the end: the final log likelihood equals the golden run's to 1e-9 relative."""
+    g = golden("Plaza2")
+    out = run("--dataset", "Plaza2", "--dataset-dir", PLAZA, "--mcmc-slam", "--mcmc-steps", "10", "--mcmc-end-steps",
+              "1000", "--sensor-range-stddev", "1", "--seed", str(g["seed"]))
+    ll = float([ln for ln in out.splitlines() if ln.startswith("MCMC-SLAM log likelihood")][0].split()[-1])
+    ref = float.fromhex(g["log_likelihood"])
+    assert abs(ll - ref) <= 1e-9 * abs(ref), (ll, ref)
+    assert "timesteps: %d landmarks: 4" % g["loader"]["T"] in out
+
+
+@pytest.mark.gpu
+def test_multi_mcmc_report(tmp_path):
+    out = subprocess.run([EXE, "--dataset", "Plaza2", "--dataset-dir", PLAZA, "--multi-mcmc", "--multi-mcmc-chains", "8",
+                          "--multi-mcmc-end-steps", "250", "--sensor-range-stddev", "4", "--seed", "7"],
+                         capture_output=True, text=True, timeout=600, cwd=tmp_path)
+    assert out.returncode == 0, out.stdout + out.stderr
+    rows = [ln.split("\t") for ln in open(tmp_path / "multi-mcmc-report.txt").read().splitlines()]
+    assert [float(r[0]) for r in rows] == [100.0, 200.0, 250.0]  # updates per chain at each report
+    best = [float(r[2]) for r in rows]
+    assert best == sorted(best)  # the best log likelihood never decreases
+    assert "Multi-MCMC-SLAM Chains: 8" in out.stdout
