@@ -216,9 +216,124 @@ MG_DEV double range_of(double dx, double dy) {
 }
 
 // ---------------------------------------------------------------------------
-// The fused observation kernel body: all lanes stream the readings of the
-// prepared segments, gather the pose translation of each reading's timestep
-// and accumulate
+// The hot loop: sum over the prepared segments of
+//   ll(|w_new - t_s|) - ll(|w_old - t_s|)                      (mcmc_slam.hpp:487-502)
+// as a software pipeline.  A reading needs two dependent loads (its record,
+// then the pose of the record's timestep), each about 1.5 us away under load,
+// against ~1000 cycles of fp64 work per group of readings; with four
+// wavefronts per SIMD that latency is only hidden if both loads of LATER
+// groups are in flight while a group is evaluated:
+//   step s:  copy out range/segment of group s        (registers R[s&1] -> C)
+//            request the poses of group s+1           (records R[(s+1)&1] -> P[(s+1)&1])
+//            find and request the records of group s+2 (-> R[s&1])
+//            evaluate group s                         (P[s&1], C)
+// The two buffer parities are written out as two half-steps so every buffer
+// is a fixed set of registers.  The segment cursor lives in registers; LDS is
+// read again only when a lane crosses into another segment.
+template <bool USIG>
+struct RatioStream {
+  static constexpr int U = 4;  // readings per lane per group
+  struct Recs {
+    uint32_t t[U], sg[U], o[U];
+    double mu[U];
+  };
+  struct Poses {
+    PoseXY p[U];
+  };
+  const Dev& d;
+  const Shared& S;
+  const PoseXY* __restrict__ pxy;
+  const uint32_t total, stride;
+  const double half_isd2;
+  uint32_t cur = 0, seg_end, seg_base;
+  double acc = 0.0;
+
+  MG_DEV RatioStream(const Dev& d_, uint32_t c, const Shared& S_, uint32_t nseg)
+      : d(d_), S(S_), pxy(d_.pxy + size_t(c) * (d_.Tcap + 1)), total(S_.segpre[nseg]), stride(blockDim.x),
+        half_isd2(0.5 * d_.usig_inv * d_.usig_inv), seg_end(S_.segpre[1]), seg_base(S_.seglo[0]) {}
+
+  MG_DEV void request_records(uint32_t i0, Recs& r) {
+    if (i0 >= total) return;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t i = i0 + u * stride;
+      if (i < total) {
+        if (i >= seg_end) {
+          do {
+            ++cur;
+            seg_end = S.segpre[cur + 1];
+          } while (i >= seg_end);
+          seg_base = S.seglo[cur] - S.segpre[cur];
+        }
+        r.o[u] = seg_base + i;
+      } else {
+        r.o[u] = S.seglo[0];
+      }
+      r.sg[u] = cur;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const ObsRec rec = d.orec[r.o[u]];
+      r.t[u] = rec.t;
+      r.mu[u] = rec.mu;
+    }
+  }
+  MG_DEV void request_poses(uint32_t i0, const Recs& r, Poses& p) {
+    if (i0 >= total) return;
+#pragma unroll
+    for (int u = 0; u < U; ++u) p.p[u] = pxy[r.t[u]];
+  }
+  MG_DEV void step(uint32_t i0, Recs& r_this, const Recs& r_next, const Poses& p_this, Poses& p_next) {
+    const uint32_t group = U * stride;
+    double mu[U], k[U];
+    uint32_t sg[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      mu[u] = r_this.mu[u];
+      sg[u] = r_this.sg[u];
+      k[u] = half_isd2;
+      if (!USIG) {
+        const double isd = d.oisd[r_this.o[u]];
+        k[u] = 0.5 * isd * isd;
+      }
+    }
+    request_poses(i0 + group, r_next, p_next);
+    request_records(i0 + 2 * group, r_this);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const double* w = S.segw[sg[u]];
+      const double ro = range_of(w[0] - p_this.p[u].x, w[1] - p_this.p[u].y);
+      const double rn = range_of(w[2] - p_this.p[u].x, w[3] - p_this.p[u].y);
+      const double term = (ro - rn) * fma(-2.0, mu[u], ro + rn) * k[u];
+      if (i0 + u * stride < total) acc += term;
+    }
+  }
+  MG_DEV double run() {
+    const uint32_t group = U * stride;
+    Recs r0, r1;
+    Poses p0, p1;
+    const uint32_t first = threadIdx.x;
+    request_records(first, r0);
+    request_records(first + group, r1);
+    request_poses(first, r0, p0);
+    for (uint32_t i0 = first; i0 < total; i0 += 2 * group) {
+      step(i0, r0, r1, p0, p1);
+      if (i0 + group < total) step(i0 + group, r1, r0, p1, p0);
+    }
+    return acc;
+  }
+};
+
+MG_DEV double eval_ratio(const Dev& d, uint32_t c, const Shared& S, uint32_t nseg) {
+  // every reading has the same sigma (what the reference's builder produces) -> no per-reading load of it
+  if (d.usig_inv > 0.0) return RatioStream<true>(d, c, S, nseg).run();
+  return RatioStream<false>(d, c, S, nseg).run();
+}
+
+// ---------------------------------------------------------------------------
+// Generic (unpipelined) form of the same loop: all lanes stream the readings
+// of the prepared segments, gather the pose translation of each reading's
+// timestep and accumulate
 //   FULL == false:  ll(|w_new - t_s|) - ll(|w_old - t_s|)     (mcmc_slam.hpp:487-502)
 //   FULL == true :  ll(|w_old - t_s|) with its constants       (slam_likelihood.hpp:48-54)
 // With z = (r - mu)/sigma the ratio term is -(zn^2 - zo^2)/2, evaluated as
@@ -302,7 +417,7 @@ MG_DEV double eval_feature_edge(const Dev& d, uint32_t c, Shared& S, uint32_t f,
   }
   __syncthreads();
   units += S.segpre[1];
-  const double acc = eval_segments<false>(d, c, S, 1);
+  const double acc = eval_ratio(d, c, S, 1);
   return block_sum(acc, S);
 }
 
@@ -408,7 +523,7 @@ MG_DEV double eval_state_edge(const Dev& d, uint32_t c, Shared& S, uint32_t t, c
       MG_STAMP(tc0);
       MG_PHASE_ADD(S, 1, tab, tc0);
       // C: stream the affected readings
-      acc += eval_segments<false>(d, c, S, nseg);
+      acc += eval_ratio(d, c, S, nseg);
       __syncthreads();
       MG_STAMP(tc1);
       MG_PHASE_ADD(S, 2, tc0, tc1);
