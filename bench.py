@@ -9,9 +9,10 @@ proposal of one chain -- summed over all chains of all GPUs of the node.
 Workload (BASELINE.json configs[2], per GPU): synthetic planar robot, 100k poses,
 1k landmarks, 1M range readings, 1024 independent chains.  A bench "step" is one
 launch of the on-device Metropolis-Hastings loop doing `--updates-per-step`
-updates (mcmc_slam::update) on every chain, followed by the periodic exchange
-of per-chain summaries (all-gather over RCCL when N > 1) and the best-chain
-arg-max.  N GPUs run N x 1024 chains (weak scaling), one process per GPU.
+updates (mcmc_slam::update) on every chain; the launch leaves one summary record
+per chain per `--report-every` updates (multi_mcmc's report interval), and the
+step ends with the exchange of those records (all-gather over RCCL when N > 1)
+and the best-chain maximum per interval.  N GPUs run N x 1024 chains (weak scaling), one process per GPU.
 
 Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 under
 python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -39,13 +40,14 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--chains", type=int, default=1024, help="chains per GPU")
-    ap.add_argument("--updates-per-step", type=int, default=100,
-                    help="updates per chain per launch; 100 = the report interval of multi_mcmc.hpp:125")
+    ap.add_argument("--updates-per-step", type=int, default=1000, help="updates per chain per launch")
+    ap.add_argument("--report-every", type=int, default=100,
+                    help="updates between per-chain summary records; 100 = the report interval of multi_mcmc.hpp:125")
     ap.add_argument("--timesteps", type=int, default=100_000)
     ap.add_argument("--landmarks", type=int, default=1000)
     ap.add_argument("--k-nearest", type=int, default=10)
     ap.add_argument("--seed", type=int, default=12345)
-    ap.add_argument("--rebuild-every", type=int, default=10, help="steps between cumulative-pose rebuilds")
+    ap.add_argument("--rebuild-every", type=int, default=1, help="steps between cumulative-pose rebuilds")
     ap.add_argument("--threads-per-chain", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -150,16 +152,18 @@ def main():
     g.load_state(problem["true_rel"], problem["landmarks"])
     g.sync()
 
-    summaries = torch.zeros((C, 2), dtype=torch.float64, device=dev)  # mcmcgpu_chain_summary records
+    intervals = -(-args.updates_per_step // args.report_every)
+    # mcmcgpu_chain_summary records, one row of C per report interval
+    summaries = torch.zeros((intervals, C, 2), dtype=torch.float64, device=dev)
     best = {"ll": float("-inf"), "chain": -1}
 
     def one_step(i):
-        g.run(args.updates_per_step)
+        g.run_reported(args.updates_per_step, args.report_every, summaries.data_ptr())
         if args.rebuild_every and (i + 1) % args.rebuild_every == 0:
             g.rebuild()
-        g.write_summaries(summaries.data_ptr())
         gathered = parallel.gather_summaries(summaries, world)  # RCCL all-gather when world > 1
-        return gathered, torch.max(gathered[:, 0])  # running best log likelihood, stays on the device
+        # best log likelihood of every report interval, stays on the device
+        return gathered[-1], torch.max(gathered[:, :, 0], dim=1).values
 
     def barrier():
         if world > 1:
@@ -224,7 +228,8 @@ def main():
                             (T, F, N, C),
                 "chains_total": C * world,
                 "updates_per_step": args.updates_per_step,
-                "parallelism": "chains sharded %dx%d, summaries all-gathered every step" % (world, C),
+                "report_every": args.report_every,
+                "parallelism": "chains sharded %dx%d, per-interval summaries all-gathered every step" % (world, C),
                 "start_state": "generating trajectory and landmark positions (mcmcgpu_load_state)",
             },
             "roofline": {

@@ -119,6 +119,15 @@ int mcmcgpu_advance(mcmcgpu_handle h, uint32_t upto, uint32_t steps_per_timestep
 int mcmcgpu_grow(mcmcgpu_handle h, uint32_t upto);
 int mcmcgpu_run(mcmcgpu_handle h, uint32_t steps);
 
+/* mcmcgpu_run in ONE launch with the report lines of multi_mcmc::completed
+ * (src/slam/multi_mcmc.hpp:121-139: a report after every 100 updates): after
+ * every `report_every` updates, and after the last one, each chain writes its
+ * mcmcgpu_chain_summary to DEVICE memory dev_out[interval * C + chain];
+ * ceil(steps / report_every) intervals.  Chains cost different amounts of work
+ * per update, so a launch lasts as long as its slowest chain; long launches
+ * keep the idle tail small without giving up the report cadence. */
+int mcmcgpu_run_reported(mcmcgpu_handle h, uint32_t steps, uint32_t report_every, void* dev_out);
+
 /* edge_log_likelihood_ratio (mcmc_slam.hpp:432-474) for one given proposal on
  * one chain, without changing the chain.  For a state edge the value includes
  * the control term (:436-438). */

@@ -54,6 +54,7 @@ EXPORTS = [
     "mcmcgpu_advance",
     "mcmcgpu_grow",
     "mcmcgpu_run",
+    "mcmcgpu_run_reported",
     "mcmcgpu_eval_llr",
     "mcmcgpu_commit",
     "mcmcgpu_rebuild",
@@ -192,6 +193,12 @@ class McmcGpu:
 
     def run(self, steps):
         self._check(self.lib.mcmcgpu_run(self.h, ctypes.c_uint32(steps)), "mcmcgpu_run")
+
+    def run_reported(self, steps, report_every, dev_ptr):
+        """`steps` updates per chain in one launch; summaries [ceil(steps/report_every)][C] to device memory."""
+        self._check(
+            self.lib.mcmcgpu_run_reported(self.h, ctypes.c_uint32(steps), ctypes.c_uint32(report_every),
+                                          ctypes.c_void_p(dev_ptr)), "mcmcgpu_run_reported")
 
     def eval_llr(self, chain, kind, index, proposed):
         q = np.zeros(3, dtype=np.float64)

@@ -86,6 +86,8 @@ struct Dev {
   uint32_t trace_cap;
   uint32_t* trace_n;  // [C]
   int32_t uniform_first;
+  mcmcgpu_chain_summary* snap_out;  // [intervals][C] per-interval summaries of the current launch, or null
+  uint32_t snap_every;
 };
 
 constexpr int kMaxSeg = 256;   // landmark segments evaluated per pass
@@ -117,7 +119,7 @@ struct Shared {
   RngState rng;
   // driver state (lane 0 only)
   int stage;
-  uint32_t tn, upto, arr, arr_end, steps_left, steps_per_ts, end_left;
+  uint32_t tn, upto, arr, arr_end, steps_left, steps_per_ts, end_left, end_done, end_inflight;
   uint32_t Tcur, nf;
   double ll;
   double Ws, Wf;  // weight totals, valid while !w_dirty
@@ -790,6 +792,21 @@ MG_DEV bool driver_arrival(const Dev& d, uint32_t c, Shared& S, uint32_t o) {
   return false;
 }
 
+// Report interval bookkeeping of a launch's end steps (multi_mcmc::completed,
+// multi_mcmc.hpp:121-139, reports after every 100 updates): when a launch runs
+// more updates than one interval, every chain leaves a summary of itself at
+// each interval boundary, so the caller gets the same report lines from one
+// long launch as from many short ones.
+MG_DEV void driver_report(const Dev& d, uint32_t c, Shared& S) {
+  if (!d.snap_out || d.snap_every == 0) return;
+  if (S.end_done % d.snap_every != 0 && S.end_left != 0) return;
+  const uint32_t slot = (S.end_done + d.snap_every - 1) / d.snap_every - 1;
+  mcmcgpu_chain_summary& r = d.snap_out[size_t(slot) * d.C + c];
+  r.log_likelihood = S.ll;
+  r.updates = uint32_t(d.n_updates[c] + S.n_upd);
+  r.accepts = uint32_t(d.n_accepts[c] + S.n_acc);
+}
+
 // Runs lane 0's program until it needs the workgroup (a request is posted in
 // S.op) or is finished (S.op = OP_END).
 MG_DEV void driver_advance(const Dev& d, uint32_t c, Shared& S) {
@@ -830,10 +847,20 @@ MG_DEV void driver_advance(const Dev& d, uint32_t c, Shared& S) {
         S.stage = ST_EDGE;
         break;
       case ST_END_STEPS:
-        while (S.end_left > 0) {
+        for (;;) {
+          if (S.end_inflight) {  // the update posted last time round has been finished by the workgroup
+            S.end_inflight = 0;
+            driver_report(d, c, S);
+          }
+          if (S.end_left == 0) break;
           --S.end_left;
           ++S.n_upd;
-          if (driver_begin_update(d, c, S)) return;
+          ++S.end_done;
+          if (driver_begin_update(d, c, S)) {
+            S.end_inflight = 1;
+            return;
+          }
+          driver_report(d, c, S);  // nothing could be updated: the step is over already
         }
         S.stage = ST_DONE;
         break;
@@ -885,11 +912,80 @@ MG_DEV void chain_state_store(const Dev& d, uint32_t c, Shared& S) {
   }
 }
 
+// The persistent kernel below is built from separately compiled pieces: the
+// serial driver (lane 0) needs many registers and may spill, the reading stream
+// must not -- a scratch reload inside its software pipeline waits on the same
+// counter as the prefetched loads and stalls it.  Each piece is therefore a
+// real call with its own register allocation.  The pieces get the kernel's
+// argument block and the chain's LDS block as address-space-qualified
+// pointers, so that after inlining inside each piece every access is still a
+// scalar load resp. an LDS operation.
+using DevArgs = const __attribute__((address_space(4))) Dev*;
+using SharedLds = __attribute__((address_space(3))) Shared*;
+#define MG_PIECE __device__ __noinline__
+
+MG_PIECE void piece_driver_advance(DevArgs dp, SharedLds sp, uint32_t c) {
+  driver_advance(*(const Dev*)dp, c, *(Shared*)sp);
+}
+
+MG_PIECE double piece_eval(DevArgs dp, SharedLds sp, uint32_t c, int op, uint32_t idx, double qx, double qy,
+                           double qth, uint32_t nf) {
+  const Dev& d = *(const Dev*)dp;
+  Shared& S = *(Shared*)sp;
+  unsigned long long units = 0;
+  double r;
+  if (op == OP_EVAL_STATE)
+    r = eval_state_edge(d, c, S, idx, Pose{qx, qy, qth}, nf, units);
+  else
+    r = eval_feature_edge(d, c, S, idx, Vec2{qx, qy}, units);
+  if (threadIdx.x == 0) {
+    S.n_units += units;
+    if (op == OP_EVAL_STATE) ++S.n_state;
+  }
+  return r;
+}
+
+// lane 0 only
+MG_PIECE void piece_finish_update(DevArgs dp, SharedLds sp, uint32_t c, uint32_t idx, double r) {
+  const Dev& d = *(const Dev*)dp;
+  Shared& S = *(Shared*)sp;
+  const bool accept = driver_finish_update(d, c, S, r);
+  S.accept = accept ? 1 : 0;
+  if (S.pending == PEND_UPDATE) {
+    if (accept) ++S.n_acc;
+  } else if (!accept) {  // rejected re-parenting update: reset the edge weight, :321-322
+    const uint32_t o = S.rp_obs;
+    const size_t fi = size_t(c) * d.Fcap + idx;
+    wt::set(d.fw + size_t(c) * d.Fcap, S.nf, idx,
+            edge_weight_from_log_pdf(range_proposal_log_pdf(d.orec[o].mu, d.osd[o], Vec2{d.fex[fi], d.fey[fi]}),
+                                     2.0, nullptr));
+    S.w_dirty = 1;
+  }
+  S.pending = PEND_NONE;
+}
+
+MG_PIECE void piece_commit(DevArgs dp, SharedLds sp, uint32_t c, uint32_t idx, double qx, double qy, double qth,
+                           uint32_t Tcur) {
+  const Dev& d = *(const Dev*)dp;
+  Shared& S = *(Shared*)sp;
+  commit_state_edge(d, c, idx, Pose{qx, qy, qth}, Tcur);
+  if (threadIdx.x == 0) {
+    const size_t ri = size_t(c) * d.Tcap + idx;
+    d.relx[ri] = qx;
+    d.rely[ri] = qy;
+    d.relth[ri] = qth;
+    S.n_moved += Tcur - idx;  // poses idx+1 .. Tcur rewritten
+  }
+}
+
 // grid = chains, block = threads_per_chain.  first_tn = the next timestep the
-// chains have not processed yet; Tcur0 = state edges grown so far.
+// chains have not processed yet; Tcur0 = state edges grown so far.  `d` must
+// stay the first parameter: the pieces read it through the argument block.
 __global__ void advance_kernel(Dev d, uint32_t first_tn, uint32_t Tcur0, uint32_t upto, uint32_t steps_per_ts,
                                uint32_t end_steps, uint32_t grow) {
   __shared__ Shared S;
+  const DevArgs dp = (DevArgs)__builtin_amdgcn_kernarg_segment_ptr();
+  const SharedLds sp = (SharedLds)&S;
   const uint32_t c = blockIdx.x;
   chain_state_load(d, c, S);
   if (threadIdx.x == 0) {
@@ -898,59 +994,31 @@ __global__ void advance_kernel(Dev d, uint32_t first_tn, uint32_t Tcur0, uint32_
     S.upto = upto;
     S.steps_per_ts = steps_per_ts;
     S.end_left = end_steps;
+    S.end_done = 0;
+    S.end_inflight = 0;
     S.stage = grow ? ST_EDGE : ST_END_STEPS;
   }
   __syncthreads();
   MG_STAMP(tk0);
   for (;;) {
     MG_STAMP(td0);
-    if (threadIdx.x == 0) driver_advance(d, c, S);
+    if (threadIdx.x == 0) piece_driver_advance(dp, sp, c);
     __syncthreads();
     MG_STAMP(td1);
     MG_PHASE_ADD(S, 0, td0, td1);
     const int op = S.op;
     if (op == OP_END) break;
     const uint32_t idx = S.idx;
-    const Pose q{S.q[0], S.q[1], S.q[2]};
+    const double qx = S.q[0], qy = S.q[1], qth = S.q[2];
     const uint32_t Tcur = S.Tcur, nf = S.nf;
-    unsigned long long units = 0;
-    double r;
-    if (op == OP_EVAL_STATE)
-      r = eval_state_edge(d, c, S, idx, q, nf, units);
-    else
-      r = eval_feature_edge(d, c, S, idx, Vec2{q.x, q.y}, units);
+    const double r = piece_eval(dp, sp, c, op, idx, qx, qy, qth, nf);
     MG_STAMP(te1);
     if (op != OP_EVAL_STATE) MG_PHASE_ADD(S, 3, td1, te1);
-    if (threadIdx.x == 0) {
-      S.n_units += units;
-      if (op == OP_EVAL_STATE) ++S.n_state;
-      const bool accept = driver_finish_update(d, c, S, r);
-      S.accept = accept ? 1 : 0;
-      if (S.pending == PEND_UPDATE) {
-        if (accept) ++S.n_acc;
-      } else if (!accept) {  // rejected re-parenting update: reset the edge weight, :321-322
-        const uint32_t o = S.rp_obs;
-        const size_t fi = size_t(c) * d.Fcap + idx;
-        wt::set(d.fw + size_t(c) * d.Fcap, S.nf, idx,
-                edge_weight_from_log_pdf(
-                    range_proposal_log_pdf(d.orec[o].mu, d.osd[o], Vec2{d.fex[fi], d.fey[fi]}), 2.0, nullptr));
-        S.w_dirty = 1;
-      }
-      S.pending = PEND_NONE;
-    }
+    if (threadIdx.x == 0) piece_finish_update(dp, sp, c, idx, r);
     __syncthreads();
     MG_STAMP(tf1);
     MG_PHASE_ADD(S, 4, te1, tf1);
-    if (op == OP_EVAL_STATE && S.accept) {
-      commit_state_edge(d, c, idx, q, Tcur);
-      if (threadIdx.x == 0) {
-        const size_t ri = size_t(c) * d.Tcap + idx;
-        d.relx[ri] = q.x;
-        d.rely[ri] = q.y;
-        d.relth[ri] = q.th;
-        S.n_moved += Tcur - idx;  // poses idx+1 .. Tcur rewritten
-      }
-    }
+    if (op == OP_EVAL_STATE && S.accept) piece_commit(dp, sp, c, idx, qx, qy, qth, Tcur);
     __syncthreads();
     MG_STAMP(tg1);
     MG_PHASE_ADD(S, 5, tf1, tg1);

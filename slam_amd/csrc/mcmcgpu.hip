@@ -383,6 +383,17 @@ int mcmcgpu_run(mcmcgpu_handle h, uint32_t steps) {
   return mcmcgpu_advance(h, h->next_timestep - 1, 0, steps);
 }
 
+int mcmcgpu_run_reported(mcmcgpu_handle h, uint32_t steps, uint32_t report_every, void* dev_out) {
+  if (!h) return MCMCGPU_ERR_ARGUMENT;
+  if (!dev_out || report_every == 0) return fail(h, MCMCGPU_ERR_ARGUMENT, "report buffer and interval are required");
+  h->d.snap_out = static_cast<mcmcgpu_chain_summary*>(dev_out);
+  h->d.snap_every = report_every;
+  const int rc = mcmcgpu_run(h, steps);
+  h->d.snap_out = nullptr;  // the launch took its copy of the descriptor
+  h->d.snap_every = 0;
+  return rc;
+}
+
 int mcmcgpu_eval_llr(mcmcgpu_handle h, uint32_t chain, int kind, uint32_t index, const double proposed[3],
                      double* out) {
   if (!h || !proposed || !out) return fail(h, MCMCGPU_ERR_ARGUMENT, "null argument");

@@ -30,6 +30,11 @@ def gather_summaries(local, world, group=None):
     likelihood).  Returns the [world*C, 2] tensor of all ranks, in global chain order."""
     if world == 1:
         return local
+    if local.dim() == 3:  # [intervals, C, 2] from mcmcgpu_run_reported -> [intervals, world*C, 2]
+        n, C, w = local.shape
+        out = torch.empty((world, n, C, w), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out.view(-1, w), local.contiguous().view(-1, w), group=group)
+        return out.permute(1, 0, 2, 3).reshape(n, world * C, w)
     out = torch.empty((local.shape[0] * world, local.shape[1]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous(), group=group)
     return out

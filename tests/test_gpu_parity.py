@@ -283,3 +283,62 @@ def test_load_state_then_run_matches_oracle():
     before = g.get_state(0)["cum"].copy()
     g.rebuild()
     assert_close(g.get_state(0)["cum"], before, 1e-11, "rebuild after many commits")
+
+
+def _summaries_to_numpy(t):
+    return t.cpu().numpy().view(capi.CHAIN_SUMMARY).reshape(t.shape[:-1])
+
+
+def test_one_reported_launch_equals_many_short_ones():
+    """multi_mcmc::completed reports every 100 updates; one long launch leaves the same report records."""
+    import torch
+
+    p = small_problem(T=300, F=10, k=3, seed=23)
+    seeds = capi.seed_sequence(3, 5)
+    C, steps, every = len(seeds), 250, 100
+    a = gpu_handle(p, seeds, trace_capacity=0)
+    a.grow(p["T"])
+    short = []
+    buf = torch.zeros((C, 2), dtype=torch.float64, device="cuda")
+    for n in (100, 100, 50):
+        a.run(n)
+        a.write_summaries(buf.data_ptr())
+        a.sync()
+        short.append(_summaries_to_numpy(buf).copy())
+    b = gpu_handle(p, seeds, trace_capacity=0)
+    b.grow(p["T"])
+    out = torch.zeros((3, C, 2), dtype=torch.float64, device="cuda")
+    b.run_reported(steps, every, out.data_ptr())
+    b.sync()
+    long = _summaries_to_numpy(out)
+    for k in range(3):
+        for name in ("log_likelihood", "updates", "accepts"):
+            assert np.array_equal(short[k][name], long[k][name]), (k, name)
+    assert list(long[2]["updates"]) == [steps] * C
+    assert np.array_equal(a.log_likelihood(), b.log_likelihood())
+
+
+def test_export_import_moves_a_chain():
+    """The best chain's state travels as a packed device buffer (what gets broadcast between GPUs)."""
+    import torch
+
+    p = small_problem(T=260, F=9, k=3, seed=29)
+    seeds = capi.seed_sequence(11, 2)
+    g = gpu_handle(p, seeds, trace_capacity=0)
+    g.grow(p["T"])
+    g.run(400)
+    g.sync()
+    ll = g.log_likelihood()
+    packed = torch.zeros(3 * p["T"] + 2 * p["F"], dtype=torch.float64, device="cuda")
+    g.export_state(0, packed.data_ptr())
+    g.import_state(1, packed.data_ptr(), float(ll[0]))
+    g.sync()
+    s0, s1 = g.get_state(0), g.get_state(1)
+    assert np.array_equal(s0["rel"], s1["rel"]) and np.array_equal(s0["feat_est"], s1["feat_est"])
+    assert_close(s1["cum"], s0["cum"], 1e-12, "cumulative poses of the imported chain")
+    assert_close(s1["state_w"], s0["state_w"], 1e-12, "state weights of the imported chain", floor=1e-300)
+    assert_close(s1["feat_w"], s0["feat_w"], 1e-12, "landmark weights of the imported chain", floor=1e-300)
+    assert g.log_likelihood()[1] == ll[0]
+    assert_close(g.full_log_likelihood()[1], ll[0], 1e-9, "imported chain: incremental vs full log likelihood")
+    g.run(100)  # both keep stepping (with their own generators)
+    g.sync()
