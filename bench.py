@@ -141,7 +141,10 @@ def main():
     problem = synthetic.make_problem(T=args.timesteps, n_landmarks=args.landmarks, k_nearest=args.k_nearest,
                                      seed=args.seed)
     T, F, N, C = problem["T"], problem["F"], problem["N"], args.chains
-    stream = torch.cuda.current_stream(dev)
+    # one explicit stream for the library's kernels, torch's reductions and the collectives:
+    # a zero stream handle would make the library create a private stream of its own
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
     g = capi.McmcGpu(C, T, F, N, device=local_rank,
                      threads_per_chain=args.threads_per_chain, stream=stream.cuda_stream)
     g.upload_problem(problem["ctrl_mean"], problem["ctrl_std"], problem["obs_t"], problem["obs_f"],
@@ -207,6 +210,15 @@ def main():
     units_total, updates_total, accepts_total = (float(x) for x in tot.tolist())
 
     if rank == 0:
+        traffic = None  # PMC counters cannot be read from inside this process: the last profiling round's figure
+        try:
+            with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+                rec = json.load(f)
+            if rec["updates_per_step"] == args.updates_per_step and rec["workload"].endswith(
+                    "%d poses, %d landmarks, %d range readings, %d chains per GPU" % (T, F, N, C)):
+                traffic = rec["traffic_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         bytes_per_launch = (d_units * BYTES_PER_UNIT + d_state * F * BYTES_PER_LANDMARK +
                             d_moved * BYTES_PER_MOVED_POSE) / max(launches, 1)
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
@@ -238,7 +250,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
                 "kernel": "advance_kernel",
                 "kernel_ms": kern_ms,
                 "launches": launches,

@@ -48,7 +48,7 @@ def main():
             print("plaza1:", bench["plaza1"])
     stats = first(os.path.join(out, "stats", "**", "*kernel_stats.csv"))
     if stats:
-        print("== rocprofv3 --kernel-trace --stats (bench, 6 timed + 2 warm-up launches of 100 updates) ==")
+        print("== rocprofv3 --kernel-trace --stats (same bench command, 2 warm-up + 6 timed launches) ==")
         with open(stats) as f:
             for r in csv.DictReader(f):
                 if float(r["Percentage"]) >= 0.01:
@@ -64,6 +64,14 @@ def main():
             print(f"FETCH_SIZE {fv * 1024:.4g} B as reported ({n} launches); gfx950 reports half of a wide "
                   f"coalesced stream, so reads are in [{fv * 1024:.4g}, {2 * fv * 1024:.4g}] B")
             print(f"WRITE_SIZE {wv * 1024:.4g} B")
+            if bench:
+                # what bench.py quotes as roofline.traffic for the same workload: reads doubled (the upper
+                # end of the bracket; the gathered 16-byte pose reads are not a calibrated pattern) + writes
+                rec = {"workload": bench["config"]["workload"], "updates_per_step": bench["config"]["updates_per_step"],
+                       "fetch_size_reported_bytes": fv * 1024, "write_size_bytes": wv * 1024,
+                       "traffic_bytes_per_launch": 2 * fv * 1024 + wv * 1024, "launches_averaged": n}
+                with open(os.path.join(out, "hbm_traffic.json"), "w") as f:
+                    json.dump(rec, f, indent=1)
     ph = os.path.join(out, "phases.txt")
     if os.path.exists(ph):
         print("== phase shares (diagnostic build, lane-0 shader-clock stamps; shares only) ==")
