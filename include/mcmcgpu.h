@@ -128,6 +128,29 @@ int mcmcgpu_run(mcmcgpu_handle h, uint32_t steps);
  * keep the idle tail small without giving up the report cadence. */
 int mcmcgpu_run_reported(mcmcgpu_handle h, uint32_t steps, uint32_t report_every, void* dev_out);
 
+/* Parallel tempering.  NO counterpart in the reference (its sampler is the
+ * case beta = 1); this is the "tempered replicas" batching mode.  The chains
+ * are grouped into ladders of `replicas` consecutive chains; the chain in
+ * temperature slot s of its ladder samples controls(x) * readings(x)^betas[s]:
+ * in the accept test of mcmc_slam.hpp:408 the readings' part of log_ratio
+ * (the sums of :476-505) is multiplied by beta, the control term of :436-438
+ * is not; with beta = 1 it is the reference's test bit for bit.  Initially slot s is held by chain ladder*replicas + s.
+ * mcmcgpu_exchange attempts, in every ladder, to swap the temperatures of the
+ * chains in slots (phase + 2k, phase + 2k + 1), phase 0 or 1, each with
+ * probability min(1, exp((beta_a - beta_b) (L_b - L_a))), L = the readings'
+ * part of the chain's log likelihood; one uniform per
+ * pair is always drawn from a library-owned generator (same engine and
+ * uniform transform as random_source, src/utility/random.hpp:11-42, seeded
+ * with `exchange_seed`), in (ladder, k) order.  States stay where they are;
+ * the log likelihoods reported everywhere are untempered.  mcmcgpu_get_ladders
+ * returns each chain's beta, the chain in each slot, each chain's L, and the
+ * totals of attempted and accepted swaps; null pointers are skipped.  init_chains resets
+ * every chain to beta = 1. */
+int mcmcgpu_set_ladders(mcmcgpu_handle h, uint32_t replicas, const double* betas, uint32_t exchange_seed);
+int mcmcgpu_exchange(mcmcgpu_handle h, uint32_t phase);
+int mcmcgpu_get_ladders(mcmcgpu_handle h, double* beta, uint32_t* slot_chain, double* reading_ll, uint64_t* attempts,
+                        uint64_t* swaps);
+
 /* edge_log_likelihood_ratio (mcmc_slam.hpp:432-474) for one given proposal on
  * one chain, without changing the chain.  For a state edge the value includes
  * the control term (:436-438). */

@@ -332,6 +332,11 @@ int ora_chain_load_state(void* p, int chain, std::uint32_t T, const double* rel,
   return 0;
 }
 
+// Inverse temperature of a tempered replica (no reference counterpart: see mcmc_slam::beta).
+void ora_chain_set_beta(void* p, int chain, double beta) {
+  static_cast<world*>(p)->chains[chain]->beta = beta;
+}
+
 // Adds a chain that does NOT listen to the data (for load_state use).
 int ora_world_add_detached_chain(void* p, std::uint32_t seed, int uniform_first) {
   struct world& w = *static_cast<struct world*>(p);

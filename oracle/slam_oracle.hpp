@@ -645,6 +645,11 @@ class mcmc_slam : public slam_data::listener, public slam_result {
 
  public:
   bool uniform_first = true;  // draw order inside range_only proposals, see range_only_model::propose
+  // Inverse temperature of a tempered replica: the chain targets controls(x) * readings(x)^beta.
+  // NOT in the reference (which is the case beta = 1, where the accept test below is the
+  // reference's bit for bit); it exists so that the GPU library's tempering mode has a checker.
+  double beta = 1.0;
+  double tempered_obs_sum = 0.0;  // readings' part of the last state-edge log ratio
   std::uint64_t units = 0;    // executions of the loop body :487-502
   std::vector<step_record>* trace = nullptr;
   unsigned steps_per_timestep = 0, end_steps = 0;  // the nested updater :200-222
@@ -707,6 +712,7 @@ class mcmc_slam : public slam_data::listener, public slam_result {
   double state_edge_log_likelihood_ratio(std::size_t t, const pose& proposed) {
     const velocity_slip_model& dist = data->control(t);
     double log_ratio = +dist.log_likelihood_of(proposed) - dist.log_likelihood_of(state_estimates.get(t));
+    tempered_obs_sum = 0.0;
     for (const auto& f : feature_estimates) {
       const auto& list = data->get_observations(f.id);
       const std::size_t middle =
@@ -714,10 +720,14 @@ class mcmc_slam : public slam_data::listener, public slam_result {
           list.begin();
       if (t < f.parent_timestep) {
         const pose delta = state_estimates.accumulate(t + 1, f.parent_timestep);
-        log_ratio += obs_likelihood_ratio(f, t, 0, middle, (proposed + delta) + f.estimate);
+        const double part = obs_likelihood_ratio(f, t, 0, middle, (proposed + delta) + f.estimate);
+        log_ratio += part;
+        tempered_obs_sum += part;
       } else {
         const pose delta = state_estimates.accumulate(t, f.parent_timestep);
-        log_ratio += obs_likelihood_ratio(f, t + 1, middle, list.size(), (-proposed + delta) + f.estimate);
+        const double part = obs_likelihood_ratio(f, t + 1, middle, list.size(), (-proposed + delta) + f.estimate);
+        log_ratio += part;
+        tempered_obs_sum += part;
       }
     }
     return log_ratio;
@@ -739,7 +749,9 @@ class mcmc_slam : public slam_data::listener, public slam_result {
     const double new_log_weight = edge_log_weight(new_pll, velocity_slip_model::proposal_dim);
     const double new_weight = std::exp(new_log_weight);
     double normaliser = 1.0;
-    double accept_log_ratio = log_ratio - proposal_log_ratio;
+    // beta != 1 (not the reference): control term at full weight, readings' sum times beta
+    const double tempered = beta == 1.0 ? log_ratio : (new_pll - old_pll) + beta * tempered_obs_sum;
+    double accept_log_ratio = tempered - proposal_log_ratio;
     if (use_edge_weight) {
       const double old_log_weight = edge_log_weight(old_pll, velocity_slip_model::proposal_dim);
       const double old_weight = std::exp(old_log_weight);
@@ -774,7 +786,7 @@ class mcmc_slam : public slam_data::listener, public slam_result {
     const double new_log_weight = edge_log_weight(new_pll, range_only_model::proposal_dim);
     const double new_weight = std::exp(new_log_weight);
     double normaliser = 1.0;
-    double accept_log_ratio = log_ratio - proposal_log_ratio;
+    double accept_log_ratio = (beta == 1.0 ? log_ratio : beta * log_ratio) - proposal_log_ratio;
     if (use_edge_weight) {
       const double old_log_weight = edge_log_weight(old_pll, range_only_model::proposal_dim);
       const double old_weight = std::exp(old_log_weight);

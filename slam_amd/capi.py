@@ -55,6 +55,9 @@ EXPORTS = [
     "mcmcgpu_grow",
     "mcmcgpu_run",
     "mcmcgpu_run_reported",
+    "mcmcgpu_set_ladders",
+    "mcmcgpu_exchange",
+    "mcmcgpu_get_ladders",
     "mcmcgpu_eval_llr",
     "mcmcgpu_commit",
     "mcmcgpu_rebuild",
@@ -199,6 +202,26 @@ class McmcGpu:
         self._check(
             self.lib.mcmcgpu_run_reported(self.h, ctypes.c_uint32(steps), ctypes.c_uint32(report_every),
                                           ctypes.c_void_p(dev_ptr)), "mcmcgpu_run_reported")
+
+    def set_ladders(self, betas, exchange_seed):
+        """Tempered replicas: ladders of len(betas) consecutive chains, slot s at inverse temperature betas[s]."""
+        b = np.ascontiguousarray(betas, dtype=np.float64)
+        self._check(self.lib.mcmcgpu_set_ladders(self.h, ctypes.c_uint32(b.size), _ptr(b), ctypes.c_uint32(exchange_seed)),
+                    "mcmcgpu_set_ladders")
+
+    def exchange(self, phase):
+        self._check(self.lib.mcmcgpu_exchange(self.h, ctypes.c_uint32(phase)), "mcmcgpu_exchange")
+
+    def ladders(self):
+        """(beta per chain, chain per temperature slot, readings' log likelihood per chain, attempted swaps,
+        accepted swaps)."""
+        beta = np.empty(self.chains, dtype=np.float64)
+        slot = np.empty(self.chains, dtype=np.uint32)
+        rll = np.empty(self.chains, dtype=np.float64)
+        att, swp = ctypes.c_uint64(), ctypes.c_uint64()
+        self._check(self.lib.mcmcgpu_get_ladders(self.h, _ptr(beta), _ptr(slot), _ptr(rll), ctypes.byref(att),
+                                                 ctypes.byref(swp)), "mcmcgpu_get_ladders")
+        return beta, slot, rll, att.value, swp.value
 
     def eval_llr(self, chain, kind, index, proposed):
         q = np.zeros(3, dtype=np.float64)

@@ -88,6 +88,11 @@ struct Dev {
   int32_t uniform_first;
   mcmcgpu_chain_summary* snap_out;  // [intervals][C] per-interval summaries of the current launch, or null
   uint32_t snap_every;
+  // tempered replicas: chain c samples p(x)^beta[c]; slot_chain[l*R + s] = the chain that holds
+  // temperature slot s of ladder l
+  double* beta;          // [C]
+  double* llc;           // [C] the control-model part of ll (tempering leaves it at full weight)
+  uint32_t* slot_chain;  // [C]
 };
 
 constexpr int kMaxSeg = 256;   // landmark segments evaluated per pass
@@ -122,6 +127,8 @@ struct Shared {
   uint32_t tn, upto, arr, arr_end, steps_left, steps_per_ts, end_left, end_done, end_inflight;
   uint32_t Tcur, nf;
   double ll;
+  double beta;    // inverse temperature of this chain (1 = the reference's sampler)
+  double llc;     // control-model part of ll
   double Ws, Wf;  // weight totals, valid while !w_dirty
   int w_dirty;
   int pending, use_weight;
@@ -604,6 +611,7 @@ MG_DEV void driver_add_state_edge(const Dev& d, uint32_t c, Shared& S) {
   wt::push_back(d.sw + size_t(c) * d.Tcap, t, edge_weight_from_log_pdf(lp, 3.0, nullptr));
   S.w_dirty = 1;
   S.ll += lp;
+  S.llc += lp;
   S.Tcur = t + 1;
 }
 
@@ -695,7 +703,10 @@ MG_DEV bool driver_finish_update(const Dev& d, uint32_t c, Shared& S, double obs
   double new_log_weight;
   const double new_weight = edge_weight_from_log_pdf(S.new_pll, dim, &new_log_weight);
   double normaliser = 1.0;
-  double accept_log_ratio = log_ratio - proposal_log_ratio;
+  // a tempered replica targets controls x readings^beta: the readings' part of the ratio is
+  // weighed by the inverse temperature; with beta = 1 this is log_ratio bit for bit
+  const double tempered = is_state ? (S.new_pll - S.old_pll) + S.beta * obs_ratio : S.beta * obs_ratio;
+  double accept_log_ratio = tempered - proposal_log_ratio;
   double* sw = d.sw + size_t(c) * d.Tcap;
   double* fw = d.fw + size_t(c) * d.Fcap;
   if (S.use_weight) {
@@ -709,6 +720,7 @@ MG_DEV bool driver_finish_update(const Dev& d, uint32_t c, Shared& S, double obs
   const bool accept = normaliser * rng_uniform(S.rng) < exp(accept_log_ratio);
   if (accept) {
     if (is_state) {
+      S.llc += S.new_pll - S.old_pll;
       wt::set(sw, S.Tcur, S.idx, new_weight);
       // the relative pose itself is stored after commit_state_edge has moved
       // the pose table (that needs the old angle)
@@ -883,6 +895,8 @@ MG_DEV void chain_state_load(const Dev& d, uint32_t c, Shared& S) {
     S.rng.saved = d.nsaved[c];
     S.nf = d.nf[c];
     S.ll = d.ll[c];
+    S.beta = d.beta[c];
+    S.llc = d.llc[c];
     S.n_upd = 0;
     S.n_acc = 0;
     S.n_units = 0;
@@ -903,6 +917,7 @@ MG_DEV void chain_state_store(const Dev& d, uint32_t c, Shared& S) {
     d.nsaved[c] = S.rng.saved;
     d.nf[c] = S.nf;
     d.ll[c] = S.ll;
+    d.llc[c] = S.llc;
     d.n_updates[c] += S.n_upd;
     d.n_accepts[c] += S.n_acc;
     d.n_units[c] += S.n_units;
@@ -1153,7 +1168,8 @@ __global__ void readout_kernel(Dev d, uint32_t c, uint32_t Tcur, double* feat_wo
 }
 
 // slam_log_likelihood (src/slam/slam_likelihood.hpp:26-58); grid = chains from `first`.
-__global__ void full_ll_kernel(Dev d, uint32_t first, uint32_t Tcur, double* out) {
+// out[c] = the log likelihood from scratch; out_controls[c] (optional) = its control-model part.
+__global__ void full_ll_kernel(Dev d, uint32_t first, uint32_t Tcur, double* out, double* out_controls) {
   __shared__ Shared S;
   const uint32_t c = first + blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
   const uint32_t segcap = nthr < uint32_t(kMaxSeg) ? nthr : uint32_t(kMaxSeg);
@@ -1163,6 +1179,11 @@ __global__ void full_ll_kernel(Dev d, uint32_t first, uint32_t Tcur, double* out
     load_control(d, t, mu, sd);
     const size_t ri = size_t(c) * d.Tcap + t;
     acc += control_log_pdf(mu, sd, Pose{d.relx[ri], d.rely[ri], d.relth[ri]});
+  }
+  if (out_controls) {
+    const double controls = block_sum(acc, S);
+    if (tid == 0) out_controls[c] = controls;
+    __syncthreads();
   }
   const uint32_t nf = d.nf[c];
   const size_t fbase = size_t(c) * d.Fcap;
@@ -1208,9 +1229,35 @@ __global__ void init_chains_kernel(Dev d, const uint32_t* seeds) {
   d.n_state_props[c] = 0;
   d.n_moved[c] = 0;
   d.errflag[c] = 0;
+  d.beta[c] = 1.0;
+  d.llc[c] = 0.0;
+  d.slot_chain[c] = c;
   if (d.trace_n) d.trace_n[c] = 0;
   d.pxy[size_t(c) * (d.Tcap + 1)] = PoseXY{0.0, 0.0};
   d.pth[size_t(c) * (d.Tcap + 1)] = 0.0;
+}
+
+// Replica exchange between neighbouring temperature slots (phase + 2k, phase + 2k + 1) of every
+// ladder of R slots; one thread per pair.  The two chains swap their temperatures (not their
+// states) with probability min(1, exp((beta_a - beta_b) (L_b - L_a))), L = the readings' part of
+// the log likelihood (ll - llc), which is what the temperatures weigh; u[pair] is the uniform of
+// that pair.  counts[0] += attempts, counts[1] += swaps.
+__global__ void exchange_kernel(Dev d, uint32_t R, uint32_t phase, const double* u, unsigned long long* counts) {
+  const uint32_t per_ladder = (R - phase) / 2;
+  const uint32_t pair = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pair >= per_ladder * (d.C / R)) return;
+  const uint32_t s = (pair / per_ladder) * R + phase + 2 * (pair % per_ladder);
+  const uint32_t a = d.slot_chain[s], b = d.slot_chain[s + 1];
+  const double ba = d.beta[a], bb = d.beta[b];
+  const double log_ratio = (ba - bb) * ((d.ll[b] - d.llc[b]) - (d.ll[a] - d.llc[a]));
+  atomicAdd(&counts[0], 1ull);
+  if (u[pair] < exp(log_ratio)) {
+    d.beta[a] = bb;
+    d.beta[b] = ba;
+    d.slot_chain[s] = b;
+    d.slot_chain[s + 1] = a;
+    atomicAdd(&counts[1], 1ull);
+  }
 }
 
 __global__ void summaries_kernel(Dev d, mcmcgpu_chain_summary* out) {

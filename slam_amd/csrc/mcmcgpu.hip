@@ -45,6 +45,11 @@ struct mcmcgpu_ctx {
   std::vector<double> h_omu;
   std::vector<EventPair> timings;
   std::vector<EventPair> free_events;
+  // tempered replicas
+  uint32_t ladder = 0;  // replicas per ladder, 0 = no ladders set
+  RngState exchange_rng{};
+  double* exch_u = nullptr;                 // [C/2 + 1] uniforms of one exchange sweep
+  unsigned long long* exch_counts = nullptr;  // attempts, swaps
   std::string error;
 };
 
@@ -192,6 +197,11 @@ int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out) {
   ALLOC(d.n_moved, C);
   ALLOC(d.errflag, C);
   ALLOC(d.trace_n, C);
+  ALLOC(d.beta, C);
+  ALLOC(d.llc, C);
+  ALLOC(d.slot_chain, C);
+  ALLOC(h->exch_u, C / 2 + 1);
+  ALLOC(h->exch_counts, 2);
   if (d.trace_cap) ALLOC(d.trace, C * d.trace_cap);
   ALLOC(h->scan_tot, C * d.NTcap);
   ALLOC(h->seed_stage, C);
@@ -316,6 +326,7 @@ int mcmcgpu_init_chains(mcmcgpu_handle h, uint32_t C, const uint32_t* seeds, con
   d.C = C;
   h->chains = C;
   h->next_timestep = 0;
+  h->ladder = 0;
   uint32_t* dseeds = h->seed_stage;
   HIP_TRY(h, hipMemcpyAsync(dseeds, seeds, size_t(C) * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
   d.n_init_u = 0;
@@ -394,6 +405,73 @@ int mcmcgpu_run_reported(mcmcgpu_handle h, uint32_t steps, uint32_t report_every
   return rc;
 }
 
+int mcmcgpu_set_ladders(mcmcgpu_handle h, uint32_t replicas, const double* betas, uint32_t exchange_seed) {
+  if (!h || !betas) return fail(h, MCMCGPU_ERR_ARGUMENT, "null argument");
+  if (h->chains == 0) return fail(h, MCMCGPU_ERR_STATE, "no chains initialised");
+  if (replicas == 0 || h->chains % replicas != 0)
+    return fail(h, MCMCGPU_ERR_ARGUMENT, "the chain count must be a multiple of the replicas per ladder");
+  for (uint32_t s = 0; s < replicas; ++s)
+    if (!(betas[s] > 0)) return fail(h, MCMCGPU_ERR_ARGUMENT, "inverse temperatures must be positive");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  std::vector<double> beta(h->chains);
+  std::vector<uint32_t> slot(h->chains);
+  for (uint32_t c = 0; c < h->chains; ++c) {
+    beta[c] = betas[c % replicas];
+    slot[c] = c;
+  }
+  HIP_TRY(h, hipMemcpyAsync(h->d.beta, beta.data(), beta.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->d.slot_chain, slot.data(), slot.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
+                            h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->exch_counts, 0, 2 * sizeof(unsigned long long), h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->ladder = replicas;
+  rng_seed(h->exchange_rng, exchange_seed);
+  return 0;
+}
+
+int mcmcgpu_exchange(mcmcgpu_handle h, uint32_t phase) {
+  if (!h) return MCMCGPU_ERR_ARGUMENT;
+  if (h->ladder == 0) return fail(h, MCMCGPU_ERR_STATE, "mcmcgpu_set_ladders has not been called");
+  if (phase > 1) return fail(h, MCMCGPU_ERR_ARGUMENT, "phase must be 0 or 1");
+  const uint32_t R = h->ladder;
+  const uint32_t pairs = ((R - phase) / 2) * (h->chains / R);
+  if (pairs == 0) return 0;
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  std::vector<double> u(pairs);
+  for (uint32_t i = 0; i < pairs; ++i) u[i] = rng_uniform(h->exchange_rng);  // always drawn, pair order
+  HIP_TRY(h, hipMemcpyAsync(h->exch_u, u.data(), u.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));  // `u` dies here
+  hipLaunchKernelGGL(exchange_kernel, dim3((pairs + 255) / 256), dim3(256), 0, h->stream, h->d, R, phase, h->exch_u,
+                     h->exch_counts);
+  HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
+int mcmcgpu_get_ladders(mcmcgpu_handle h, double* beta, uint32_t* slot_chain, double* reading_ll, uint64_t* attempts,
+                        uint64_t* swaps) {
+  if (!h) return MCMCGPU_ERR_ARGUMENT;
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  unsigned long long counts[2] = {0, 0};
+  if (beta)
+    HIP_TRY(h, hipMemcpyAsync(beta, h->d.beta, h->chains * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (slot_chain)
+    HIP_TRY(h, hipMemcpyAsync(slot_chain, h->d.slot_chain, h->chains * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                              h->stream));
+  std::vector<double> ll, llc;
+  if (reading_ll) {
+    ll.resize(h->chains);
+    llc.resize(h->chains);
+    HIP_TRY(h, hipMemcpyAsync(ll.data(), h->d.ll, h->chains * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(llc.data(), h->d.llc, h->chains * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  }
+  HIP_TRY(h, hipMemcpyAsync(counts, h->exch_counts, sizeof counts, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  for (uint32_t c = 0; reading_ll && c < h->chains; ++c) reading_ll[c] = ll[c] - llc[c];
+  if (attempts) *attempts = counts[0];
+  if (swaps) *swaps = counts[1];
+  return 0;
+}
+
 int mcmcgpu_eval_llr(mcmcgpu_handle h, uint32_t chain, int kind, uint32_t index, const double proposed[3],
                      double* out) {
   if (!h || !proposed || !out) return fail(h, MCMCGPU_ERR_ARGUMENT, "null argument");
@@ -463,7 +541,8 @@ int mcmcgpu_full_log_likelihood(mcmcgpu_handle h, double* out) {
   double* dout = nullptr;
   // the per-chain results go to the tile-total buffer of the rebuild scan (idle here)
   dout = reinterpret_cast<double*>(h->scan_tot);
-  hipLaunchKernelGGL(full_ll_kernel, dim3(h->chains), dim3(h->nthreads), 0, h->stream, h->d, 0u, edges_grown(h), dout);
+  hipLaunchKernelGGL(full_ll_kernel, dim3(h->chains), dim3(h->nthreads), 0, h->stream, h->d, 0u, edges_grown(h), dout,
+                     static_cast<double*>(nullptr));
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemcpyAsync(out, dout, sizeof(double) * h->chains, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -690,7 +769,7 @@ int mcmcgpu_load_state(mcmcgpu_handle h, uint32_t first, uint32_t count, const d
     HIP_TRY(h, hipGetLastError());
   }
   hipLaunchKernelGGL(reweigh_kernel, dim3(count), dim3(256), 0, h->stream, d, first, T);
-  hipLaunchKernelGGL(full_ll_kernel, dim3(count), dim3(h->nthreads), 0, h->stream, d, first, T, d.ll);
+  hipLaunchKernelGGL(full_ll_kernel, dim3(count), dim3(h->nthreads), 0, h->stream, d, first, T, d.ll, d.llc);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipStreamSynchronize(h->stream));  // host staging vector dies here
   return 0;
