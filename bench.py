@@ -39,11 +39,16 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--chains", type=int, default=1024, help="chains per GPU")
-    ap.add_argument("--updates-per-step", type=int, default=1000, help="updates per chain per launch")
+    ap.add_argument("--workload", choices=["chains", "tempering"], default="chains",
+                    help="chains: BASELINE.json configs[2] (the headline); tempering: configs[4], one ladder of "
+                         "tempered replicas per GPU on a 1M-pose trajectory with a replica exchange after every launch")
+    ap.add_argument("--chains", type=int, default=None, help="chains per GPU (1024; tempering: 64)")
+    ap.add_argument("--updates-per-step", type=int, default=None,
+                    help="updates per chain per launch (1000; tempering: 200)")
     ap.add_argument("--report-every", type=int, default=100,
                     help="updates between per-chain summary records; 100 = the report interval of multi_mcmc.hpp:125")
-    ap.add_argument("--timesteps", type=int, default=100_000)
+    ap.add_argument("--timesteps", type=int, default=None, help="poses (100 000; tempering: 1 000 000)")
+    ap.add_argument("--beta-min", type=float, default=0.01, help="tempering: coldest..hottest = 1..beta_min, geometric")
     ap.add_argument("--landmarks", type=int, default=1000)
     ap.add_argument("--k-nearest", type=int, default=10)
     ap.add_argument("--seed", type=int, default=12345)
@@ -52,7 +57,19 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-plaza", action="store_true")
-    return ap.parse_args()
+    args = ap.parse_args()
+    tempering = args.workload == "tempering"
+    if args.chains is None:
+        args.chains = 64 if tempering else 1024
+    if args.updates_per_step is None:
+        args.updates_per_step = 200 if tempering else 1000
+    if args.timesteps is None:
+        args.timesteps = 1_000_000 if tempering else 100_000
+    if tempering:
+        if args.threads_per_chain == 0:
+            args.threads_per_chain = 1024  # few, long chains: the widest workgroup per chain
+        args.no_cpu_baseline = args.no_plaza = True
+    return args
 
 
 def cpu_baseline(problem, seed, target_seconds):
@@ -138,8 +155,9 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
+    tempering = args.workload == "tempering"
     problem = synthetic.make_problem(T=args.timesteps, n_landmarks=args.landmarks, k_nearest=args.k_nearest,
-                                     seed=args.seed)
+                                     seed=args.seed, max_tries=2 if tempering else 8)
     T, F, N, C = problem["T"], problem["F"], problem["N"], args.chains
     # one explicit stream for the library's kernels, torch's reductions and the collectives:
     # a zero stream handle would make the library create a private stream of its own
@@ -153,6 +171,8 @@ def main():
     all_seeds = capi.seed_sequence(args.seed + 2, C * world)
     g.init_chains(parallel.shard_seeds(all_seeds, C, rank))
     g.load_state(problem["true_rel"], problem["landmarks"])
+    if tempering:  # one ladder per GPU: slot 0 is the untempered chain
+        g.set_ladders(np.geomspace(1.0, args.beta_min, C), exchange_seed=args.seed + 3 + rank)
     g.sync()
 
     intervals = -(-args.updates_per_step // args.report_every)
@@ -164,6 +184,8 @@ def main():
         g.run_reported(args.updates_per_step, args.report_every, summaries.data_ptr())
         if args.rebuild_every and (i + 1) % args.rebuild_every == 0:
             g.rebuild()
+        if tempering:
+            g.exchange(i % 2)
         gathered = parallel.gather_summaries(summaries, world)  # RCCL all-gather when world > 1
         # best log likelihood of every report interval, stays on the device
         return gathered[-1], torch.max(gathered[:, :, 0], dim=1).values
@@ -236,8 +258,8 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "synthetic planar robot: %d poses, %d landmarks, %d range readings, %d chains per GPU" %
-                            (T, F, N, C),
+                "workload": "synthetic planar robot: %d poses, %d landmarks, %d range readings, %d %s per GPU" %
+                            (T, F, N, C, "tempered replicas (one ladder)" if tempering else "chains"),
                 "chains_total": C * world,
                 "updates_per_step": args.updates_per_step,
                 "report_every": args.report_every,
@@ -262,6 +284,11 @@ def main():
             "best_log_likelihood": best["ll"],
             "best_chain": best["chain"],
         }
+        if tempering:
+            beta, slot, _, attempts, swaps = g.ladders()
+            out["config"]["beta"] = "geometric 1 .. %g over %d slots, exchange after every launch" % (args.beta_min, C)
+            out["config"]["threads_per_chain"] = args.threads_per_chain
+            out["exchange"] = {"attempts": attempts, "swaps": swaps, "chain_at_beta_1": int(slot[0])}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(problem, all_seeds[0], args.cpu_seconds)
         if world == 1 and not args.no_plaza:
