@@ -207,6 +207,31 @@ int mcmcgpu_write_summaries(mcmcgpu_handle h, void* dev_out);
 int mcmcgpu_export_state(mcmcgpu_handle h, uint32_t chain, void* dev_out);
 int mcmcgpu_import_state(mcmcgpu_handle h, uint32_t chain, const void* dev_in, double log_likelihood);
 
+/* multi_mcmc::get_average = average_slam_result over the chains
+ * (src/slam/multi_mcmc.hpp:71-73, src/slam/average_slam_result.hpp:58-110).
+ * What is averaged, packed as doubles: for t < T the accumulated pose
+ * trajectory.accumulate(t+1) as (x, y, angle) -> [T][3], then each landmark's
+ * world position -> [F'][2] (F' = landmarks met so far).  The reference keeps
+ * the first result's vectors as `base`, sums subtract(base, v) over the others
+ * (angle differences wrapped) and returns subtract(base, sum / n)
+ * (average_slam_result.hpp:27-54).
+ *   mcmcgpu_average_base   writes one chain's vectors to DEVICE memory;
+ *   mcmcgpu_average_sum    writes the sum over this handle's chains (in chain
+ *                          order, leaving out `skip_chain` unless it is < 0) of
+ *                          subtract(base, v) to DEVICE memory -- across GPUs
+ *                          these sums are all-reduced (SUM);
+ *   mcmcgpu_average_finish turns `base` into the average in place, n =
+ *                          total_chains over all GPUs;
+ *   mcmcgpu_get_average    does all three for this handle's chains (base =
+ *                          chain 0) and copies the result to HOST memory; the
+ *                          caller rebuilds the relative-pose tree from the
+ *                          accumulated poses as push_back_accumulated does
+ *                          (src/utility/bitree.hpp:294-300). */
+int mcmcgpu_average_base(mcmcgpu_handle h, uint32_t chain, void* dev_base);
+int mcmcgpu_average_sum(mcmcgpu_handle h, const void* dev_base, int32_t skip_chain, void* dev_sum);
+int mcmcgpu_average_finish(mcmcgpu_handle h, void* dev_base, const void* dev_sum, uint32_t total_chains);
+int mcmcgpu_get_average(mcmcgpu_handle h, double* cumulative_poses, double* features_world);
+
 /* Puts chains [first, first+count) into one given state with the WHOLE uploaded
  * problem already seen (restoring a checkpoint; also how a run is started from
  * a known estimate, e.g. another back end's result as g2o_slam::reinitialise

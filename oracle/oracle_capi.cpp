@@ -360,6 +360,23 @@ double ora_chain_eval(void* p, int chain, int kind, std::uint32_t index, const d
   return r;
 }
 
+// multi_mcmc::get_average over all chains of the world (src/slam/multi_mcmc.hpp:71-73):
+// accumulated [T][3], features [F][2] in ascending landmark id.
+void ora_world_average(void* p, double* accumulated, double* features) {
+  world& w = *static_cast<world*>(p);
+  std::vector<const slam_result*> results;
+  for (const auto& c : w.chains) results.push_back(c.get());
+  const averaged_result avg = average_slam_result(results);
+  for (std::size_t t = 0; t < avg.accumulated.size(); ++t)
+    for (int i = 0; i < 3; ++i) accumulated[3 * t + i] = avg.accumulated[t][i];
+  std::size_t k = 0;
+  for (const auto& kv : avg.features) {
+    features[2 * k] = kv.second[0];
+    features[2 * k + 1] = kv.second[1];
+    ++k;
+  }
+}
+
 // n successive 32-bit engine draws from random_source(seed): the chain seeds
 // of multi_mcmc (src/slam/multi_mcmc.hpp:160-166) and the module seeds of
 // src/main.cpp:133-147.

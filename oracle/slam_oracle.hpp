@@ -58,6 +58,13 @@ inline double wrap_angle(double angle) {
   return angle;
 }
 
+// Sine and cosine of one angle, as a pair.  Wherever the reference needs both (Eigen's
+// Rotation2D applied to a vector, position::polar, velocity_slip_model::inv_observe) an optimising
+// g++ turns the two calls into ONE sincos call, and glibc's sincos differs from its sin / cos by
+// an ulp for about one argument in a thousand.  The pairing is therefore written out, so that the
+// oracle's bits do not depend on what the compiler happens to inline where.
+inline void sin_cos(double angle, double& s, double& c) { ::sincos(angle, &s, &c); }
+
 // ---------------------------------------------------------------------------
 // src/planar_robot/position.hpp:12-47
 struct position {
@@ -65,7 +72,9 @@ struct position {
   static position cartesian(double x, double y) { return {x, y}; }
   // position.hpp:27-29
   static position polar(double dist, double dir) {
-    return {dist * std::cos(dir), dist * std::sin(dir)};
+    double s, c;
+    sin_cos(dir, s, c);
+    return {dist * c, dist * s};
   }
   double distance_squared() const { return x * x + y * y; }          // :35
   double distance() const { return std::sqrt(distance_squared()); }  // :33
@@ -82,7 +91,8 @@ struct pose {
 
   // pose.hpp:67-71   translation += R(th) * p.translation; th += p.th
   pose& operator+=(const pose& p) {
-    const double s = std::sin(th), c = std::cos(th);
+    double s, c;
+    sin_cos(th, s, c);
     const double rx = c * p.x - s * p.y;
     const double ry = s * p.x + c * p.y;
     x += rx;
@@ -93,7 +103,8 @@ struct pose {
   // pose.hpp:73-76   (R(-th) * (-t), -th)
   pose operator-() const {
     const double ith = -th;
-    const double s = std::sin(ith), c = std::cos(ith);
+    double s, c;
+    sin_cos(ith, s, c);
     const double nx = -x, ny = -y;
     return {c * nx - s * ny, s * nx + c * ny, ith};
   }
@@ -101,7 +112,8 @@ struct pose {
 inline pose operator+(pose a, const pose& b) { return a += b; }  // pose.hpp:81-83
 // pose.hpp:85-87
 inline position operator+(const pose& p, const position& o) {
-  const double s = std::sin(p.th), c = std::cos(p.th);
+  double s, c;
+  sin_cos(p.th, s, c);
   const double rx = c * o.x - s * o.y;
   const double ry = s * o.x + c * o.y;
   return {p.x + rx, p.y + ry};
@@ -337,8 +349,11 @@ struct velocity_slip_model : independent_normal<3> {
   // :51-63
   static pose inv_observe(const double* control) {
     const double s = control[0], alpha = control[1], beta = control[2], r = s / alpha;
-    if (std::isfinite(r))
-      return pose::cartesian(r * std::sin(alpha), r - r * std::cos(alpha), alpha + beta);
+    if (std::isfinite(r)) {
+      double sa, ca;
+      sin_cos(alpha, sa, ca);
+      return pose::cartesian(r * sa, r - r * ca, alpha + beta);
+    }
     return pose::cartesian(s, 0.0, beta);
   }
   // proposal_dist :131-153
@@ -1008,6 +1023,66 @@ class multi_mcmc : public slam_data::listener {
     }
   }
 };
+
+// src/slam/average_slam_result.hpp:27-110.  The reference returns a slam_result whose trajectory
+// is rebuilt with push_back_accumulated; what it averages, and what is returned here, are the
+// accumulated poses trajectory.accumulate(t+1) as (x, y, angle) and the landmark positions
+// relative to the initial state.  avg_acc (:27-54): the first result is the base, the others add
+// subtract(base, v) (pose: angle difference wrapped, pose.hpp:63-65; position: plain), and the
+// average is subtract(base, sum / n).
+struct averaged_result {
+  std::vector<std::array<double, 3>> accumulated;  // [T]
+  std::map<std::size_t, std::array<double, 2>> features;
+};
+inline averaged_result average_slam_result(const std::vector<const slam_result*>& results) {
+  struct acc3 {
+    std::array<double, 3> base{}, sum{};
+    unsigned n = 0;
+  };
+  struct acc2 {
+    std::array<double, 2> base{}, sum{};
+    unsigned n = 0;
+  };
+  std::vector<acc3> state_avgs;
+  std::map<std::size_t, acc2> feature_avgs;
+  for (const slam_result* r : results) {
+    const pose initial_state = r->get_initial_state();
+    const auto& trajectory = r->get_trajectory();
+    if (state_avgs.size() < trajectory.size()) state_avgs.resize(trajectory.size());
+    for (std::size_t t = 0; t < trajectory.size(); ++t) {
+      const pose p = trajectory.accumulate(t + 1);
+      const std::array<double, 3> v{p.x, p.y, p.th};
+      acc3& a = state_avgs[t];
+      if (a.n == 0) {
+        a.base = v;
+      } else {
+        a.sum[0] += a.base[0] - v[0];
+        a.sum[1] += a.base[1] - v[1];
+        a.sum[2] += wrap_angle(a.base[2] - v[2]);
+      }
+      ++a.n;
+    }
+    for (const auto& id_feature : r->get_feature_map()) {
+      const position q = -initial_state + id_feature.second;
+      acc2& a = feature_avgs[id_feature.first];
+      if (a.n == 0) {
+        a.base = {q.x, q.y};
+      } else {
+        a.sum[0] += a.base[0] - q.x;
+        a.sum[1] += a.base[1] - q.y;
+      }
+      ++a.n;
+    }
+  }
+  averaged_result out;
+  for (const acc3& a : state_avgs)
+    out.accumulated.push_back(
+        {a.base[0] - a.sum[0] / a.n, a.base[1] - a.sum[1] / a.n, wrap_angle(a.base[2] - a.sum[2] / a.n)});
+  for (const auto& kv : feature_avgs)
+    out.features[kv.first] = {kv.second.base[0] - kv.second.sum[0] / kv.second.n,
+                              kv.second.base[1] - kv.second.sum[1] / kv.second.n};
+  return out;
+}
 
 // src/main.cpp:133-147 -- module seeds are six successive engine draws, made
 // unconditionally, in this order.

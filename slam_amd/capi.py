@@ -69,6 +69,10 @@ EXPORTS = [
     "mcmcgpu_get_traffic_counters",
     "mcmcgpu_get_trace",
     "mcmcgpu_write_summaries",
+    "mcmcgpu_average_base",
+    "mcmcgpu_average_sum",
+    "mcmcgpu_average_finish",
+    "mcmcgpu_get_average",
     "mcmcgpu_export_state",
     "mcmcgpu_import_state",
     "mcmcgpu_load_state",
@@ -222,6 +226,26 @@ class McmcGpu:
         self._check(self.lib.mcmcgpu_get_ladders(self.h, _ptr(beta), _ptr(slot), _ptr(rll), ctypes.byref(att),
                                                  ctypes.byref(swp)), "mcmcgpu_get_ladders")
         return beta, slot, rll, att.value, swp.value
+
+    def average_base(self, chain, dev_ptr):
+        self._check(self.lib.mcmcgpu_average_base(self.h, ctypes.c_uint32(chain), ctypes.c_void_p(dev_ptr)),
+                    "mcmcgpu_average_base")
+
+    def average_sum(self, base_ptr, skip_chain, sum_ptr):
+        self._check(self.lib.mcmcgpu_average_sum(self.h, ctypes.c_void_p(base_ptr), ctypes.c_int32(skip_chain),
+                                                 ctypes.c_void_p(sum_ptr)), "mcmcgpu_average_sum")
+
+    def average_finish(self, base_ptr, sum_ptr, total_chains):
+        self._check(self.lib.mcmcgpu_average_finish(self.h, ctypes.c_void_p(base_ptr), ctypes.c_void_p(sum_ptr),
+                                                    ctypes.c_uint32(total_chains)), "mcmcgpu_average_finish")
+
+    def average(self):
+        """multi_mcmc::get_average over this handle's chains: (accumulated poses [T,3], landmarks [F',2])."""
+        T, F, _ = self.dims()
+        cum = np.empty((T, 3), dtype=np.float64)
+        feat = np.empty((F, 2), dtype=np.float64)
+        self._check(self.lib.mcmcgpu_get_average(self.h, _ptr(cum), _ptr(feat)), "mcmcgpu_get_average")
+        return cum, feat
 
     def eval_llr(self, chain, kind, index, proposed):
         q = np.zeros(3, dtype=np.float64)

@@ -1260,6 +1260,74 @@ __global__ void exchange_kernel(Dev d, uint32_t R, uint32_t phase, const double*
   }
 }
 
+// average_slam_result (src/slam/average_slam_result.hpp:58-110) in two kernels.  The vectors that
+// are averaged: per timestep t the accumulated pose trajectory.accumulate(t+1) as (x, y, angle)
+// (:81-83), per landmark its world position (:85-87, initial state = identity); packed as
+// [Tcur][3] then [nf][2] doubles.  One thread per vector.
+MG_DEV void average_vector(const Dev& d, uint32_t c, uint32_t Tcur, uint32_t e, double v[3]) {
+  if (e < Tcur) {
+    const Pose p = world_pose(d, c, e + 1);
+    v[0] = p.x;
+    v[1] = p.y;
+    v[2] = p.th;
+  } else {
+    const size_t fi = size_t(c) * d.Fcap + (e - Tcur);
+    const Vec2 w = act(world_pose(d, c, d.fpt[fi]), Vec2{d.fex[fi], d.fey[fi]});
+    v[0] = w.x;
+    v[1] = w.y;
+    v[2] = 0.0;
+  }
+}
+
+// The first result's vectors: avg_acc::base (:42-44).
+__global__ void average_base_kernel(Dev d, uint32_t c, uint32_t Tcur, uint32_t nf, double* base) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= Tcur + nf) return;
+  double v[3];
+  average_vector(d, c, Tcur, e, v);
+  if (e < Tcur) {
+    base[3 * size_t(e)] = v[0];
+    base[3 * size_t(e) + 1] = v[1];
+    base[3 * size_t(e) + 2] = v[2];
+  } else {
+    base[3 * size_t(Tcur) + 2 * size_t(e - Tcur)] = v[0];
+    base[3 * size_t(Tcur) + 2 * size_t(e - Tcur) + 1] = v[1];
+  }
+}
+
+// sum_innov (:45-46): sum over this handle's chains, in chain order and without `skip`, of
+// subtract(base, vector) -- componentwise, the angle difference wrapped (pose.hpp:63-65).
+__global__ void average_sum_kernel(Dev d, uint32_t Tcur, uint32_t nf, const double* base, int32_t skip, double* sum) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= Tcur + nf) return;
+  const bool is_pose = e < Tcur;
+  const size_t at = is_pose ? 3 * size_t(e) : 3 * size_t(Tcur) + 2 * size_t(e - Tcur);
+  const double b0 = base[at], b1 = base[at + 1], b2 = is_pose ? base[at + 2] : 0.0;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (uint32_t c = 0; c < d.C; ++c) {
+    if (int32_t(c) == skip) continue;
+    double v[3];
+    average_vector(d, c, Tcur, e, v);
+    s0 += b0 - v[0];
+    s1 += b1 - v[1];
+    if (is_pose) s2 += wrap_angle(b2 - v[2]);
+  }
+  sum[at] = s0;
+  sum[at + 1] = s1;
+  if (is_pose) sum[at + 2] = s2;
+}
+
+// avg_acc::get (:50-53): subtract(base, sum_innov / n), in place in `base`.
+__global__ void average_finish_kernel(uint32_t Tcur, uint32_t nf, double* base, const double* sum, double n) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= Tcur + nf) return;
+  const bool is_pose = e < Tcur;
+  const size_t at = is_pose ? 3 * size_t(e) : 3 * size_t(Tcur) + 2 * size_t(e - Tcur);
+  base[at] = base[at] - sum[at] / n;
+  base[at + 1] = base[at + 1] - sum[at + 1] / n;
+  if (is_pose) base[at + 2] = wrap_angle(base[at + 2] - sum[at + 2] / n);
+}
+
 __global__ void summaries_kernel(Dev d, mcmcgpu_chain_summary* out) {
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= d.C) return;

@@ -205,7 +205,7 @@ int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out) {
   if (d.trace_cap) ALLOC(d.trace, C * d.trace_cap);
   ALLOC(h->scan_tot, C * d.NTcap);
   ALLOC(h->seed_stage, C);
-  h->scratch_doubles = 5 * (size_t(d.Tcap) + 1) + 4 * size_t(d.Fcap) + 16;
+  h->scratch_doubles = 6 * (size_t(d.Tcap) + 1) + 4 * size_t(d.Fcap) + 16;
   ALLOC(h->scratch, h->scratch_doubles);
 #undef ALLOC
   if (rc) {
@@ -701,6 +701,80 @@ int mcmcgpu_export_state(mcmcgpu_handle h, uint32_t chain, void* dev_out) {
   HIP_TRY(h, cp(o + 2 * T, d.relth + size_t(chain) * d.Tcap, T));
   HIP_TRY(h, cp(o + 3 * T, d.fex + size_t(chain) * d.Fcap, F));
   HIP_TRY(h, cp(o + 3 * T + F, d.fey + size_t(chain) * d.Fcap, F));
+  return 0;
+}
+
+namespace {
+// Landmarks the chains have met so far (the same for every chain: it depends on the data only).
+int chains_features(mcmcgpu_handle h, uint32_t* nf) {
+  *nf = 0;
+  if (h->chains == 0) return 0;
+  HIP_TRY(h, hipMemcpyAsync(nf, h->d.nf, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+}  // namespace
+
+int mcmcgpu_average_base(mcmcgpu_handle h, uint32_t chain, void* dev_base) {
+  if (!h || !dev_base) return fail(h, MCMCGPU_ERR_ARGUMENT, "null argument");
+  if (chain >= h->chains) return fail(h, MCMCGPU_ERR_ARGUMENT, "chain out of range");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  uint32_t nf = 0;
+  if (int rc = chains_features(h, &nf)) return rc;
+  const uint32_t T = edges_grown(h), n = T + nf;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(average_base_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d, chain, T, nf,
+                     static_cast<double*>(dev_base));
+  HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
+int mcmcgpu_average_sum(mcmcgpu_handle h, const void* dev_base, int32_t skip_chain, void* dev_sum) {
+  if (!h || !dev_base || !dev_sum) return fail(h, MCMCGPU_ERR_ARGUMENT, "null argument");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  uint32_t nf = 0;
+  if (int rc = chains_features(h, &nf)) return rc;
+  const uint32_t T = edges_grown(h), n = T + nf;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(average_sum_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d, T, nf,
+                     static_cast<const double*>(dev_base), skip_chain, static_cast<double*>(dev_sum));
+  HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
+int mcmcgpu_average_finish(mcmcgpu_handle h, void* dev_base, const void* dev_sum, uint32_t total_chains) {
+  if (!h || !dev_base || !dev_sum) return fail(h, MCMCGPU_ERR_ARGUMENT, "null argument");
+  if (total_chains == 0) return fail(h, MCMCGPU_ERR_ARGUMENT, "total_chains must be positive");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  uint32_t nf = 0;
+  if (int rc = chains_features(h, &nf)) return rc;
+  const uint32_t T = edges_grown(h), n = T + nf;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(average_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, T, nf,
+                     static_cast<double*>(dev_base), static_cast<const double*>(dev_sum), double(total_chains));
+  HIP_TRY(h, hipGetLastError());
+  return 0;
+}
+
+int mcmcgpu_get_average(mcmcgpu_handle h, double* cumulative_poses, double* features_world) {
+  if (!h) return MCMCGPU_ERR_ARGUMENT;
+  if (h->chains == 0) return fail(h, MCMCGPU_ERR_STATE, "no chains initialised");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  uint32_t nf = 0;
+  if (int rc = chains_features(h, &nf)) return rc;
+  const size_t T = edges_grown(h), n = 3 * T + 2 * size_t(nf);
+  if (2 * n > h->scratch_doubles) return fail(h, MCMCGPU_ERR_CAPACITY, "internal staging buffer too small");
+  double* base = h->scratch;
+  double* sum = h->scratch + n;
+  if (int rc = mcmcgpu_average_base(h, 0, base)) return rc;
+  if (int rc = mcmcgpu_average_sum(h, base, 0, sum)) return rc;
+  if (int rc = mcmcgpu_average_finish(h, base, sum, h->chains)) return rc;
+  if (cumulative_poses && T)
+    HIP_TRY(h, hipMemcpyAsync(cumulative_poses, base, 3 * T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (features_world && nf)
+    HIP_TRY(h, hipMemcpyAsync(features_world, base + 3 * T, 2 * size_t(nf) * sizeof(double), hipMemcpyDeviceToHost,
+                              h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
   return 0;
 }
 

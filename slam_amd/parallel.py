@@ -60,3 +60,25 @@ def counts_of(all_summaries):
     """(updates, accepts) per chain, decoded from the second 8 bytes of each record."""
     raw = all_summaries[:, 1].contiguous().cpu().numpy().view(np.uint32).reshape(-1, 2)
     return raw[:, 0].copy(), raw[:, 1].copy()
+
+
+def average_over_ranks(g, chains_per_rank, rank, world, device, group=None):
+    """multi_mcmc::get_average (src/slam/multi_mcmc.hpp:71-73) over the chains of all ranks.  The
+    reference's accumulator keeps the first chain's vectors as its base and sums the wrapped
+    differences of the others (src/slam/average_slam_result.hpp:27-54): rank 0 broadcasts the base
+    (global chain 0), every rank sums over its own chains on its GPU, one all-reduce (SUM) of
+    3T + 2F doubles joins them.  Returns (accumulated poses [T,3], landmarks [F,2]) on `device`;
+    `g` must run on torch's current stream."""
+    T, F, _ = g.dims()
+    n = 3 * T + 2 * F
+    base = torch.zeros(n, dtype=torch.float64, device=device)
+    total = torch.zeros(n, dtype=torch.float64, device=device)
+    if rank == 0:
+        g.average_base(0, base.data_ptr())
+    if world > 1:
+        dist.broadcast(base, src=0, group=group)
+    g.average_sum(base.data_ptr(), 0 if rank == 0 else -1, total.data_ptr())
+    if world > 1:
+        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+    g.average_finish(base.data_ptr(), total.data_ptr(), chains_per_rank * world)
+    return base[:3 * T].view(T, 3), base[3 * T:].view(F, 2)

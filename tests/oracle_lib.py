@@ -42,7 +42,7 @@ def lib():
         L.ora_chain_trace_size.restype = ctypes.c_uint32
         for name in ("ora_world_dims", "ora_world_get_input", "ora_chain_trace_enable", "ora_chain_trace_get",
                      "ora_chain_dims", "ora_chain_get_state", "ora_chain_get_weight_nodes", "ora_chain_get_rng",
-                     "ora_seed_sequence", "ora_uniform_sequence", "ora_chain_set_beta"):
+                     "ora_seed_sequence", "ora_uniform_sequence", "ora_chain_set_beta", "ora_world_average"):
             getattr(L, name).restype = None
         _lib = L
     return _lib
@@ -133,6 +133,12 @@ class World:
                                          _p(fid), _p(fw))
         if rc != 0:
             raise RuntimeError(f"ora_chain_load_state failed ({rc}): {self.L.ora_world_error(self.w).decode()}")
+
+    def average(self, T, F):
+        """multi_mcmc::get_average over all chains: accumulated poses [T,3], landmarks [F,2] by ascending id."""
+        acc, feat = np.empty((T, 3)), np.empty((F, 2))
+        self.L.ora_world_average(self.w, _p(acc), _p(feat))
+        return acc, feat
 
     def set_beta(self, chain, beta):
         self.L.ora_chain_set_beta(self.w, chain, ctypes.c_double(beta))

@@ -342,3 +342,48 @@ def test_export_import_moves_a_chain():
     assert_close(g.full_log_likelihood()[1], ll[0], 1e-9, "imported chain: incremental vs full log likelihood")
     g.run(100)  # both keep stepping (with their own generators)
     g.sync()
+
+
+def test_average_over_chains_matches_oracle():
+    """multi_mcmc::get_average: on one handle, and split over two handles the way two GPUs would."""
+    import torch
+
+    p = small_problem(T=250, F=9, k=3, seed=21)
+    seeds = capi.seed_sequence(31, 6)
+    steps = 300
+    w = oracle_world(p, seeds, trace=False)
+    w.replay(p["T"])
+    for c in range(len(seeds)):
+        assert w.update(c, steps) >= 0
+    acc_o, feat_o = w.average(p["T"], p["F"])
+    g = gpu_handle(p, seeds, trace_capacity=0)
+    g.grow(p["T"])
+    g.run(steps)
+    acc_g, feat_g = g.average()
+    assert_close(acc_g, acc_o, REL, "averaged accumulated poses")
+    assert_close(feat_g, feat_o, REL, "averaged landmarks")
+    # chains 0-2 on one handle, 3-5 on another: base from the first, sums added, finished on either
+    n = 3 * p["T"] + 2 * p["F"]
+    halves = []
+    for part in (seeds[:3], seeds[3:]):
+        h = gpu_handle(p, part, trace_capacity=0)
+        h.grow(p["T"])
+        h.run(steps)
+        h.sync()
+        halves.append(h)
+    base = torch.zeros(n, dtype=torch.float64, device="cuda")
+    sums = [torch.zeros(n, dtype=torch.float64, device="cuda") for _ in halves]
+    torch.cuda.synchronize()
+    halves[0].average_base(0, base.data_ptr())
+    halves[0].sync()
+    halves[0].average_sum(base.data_ptr(), 0, sums[0].data_ptr())
+    halves[1].average_sum(base.data_ptr(), -1, sums[1].data_ptr())
+    halves[0].sync()
+    halves[1].sync()
+    total = sums[0] + sums[1]
+    torch.cuda.synchronize()
+    halves[1].average_finish(base.data_ptr(), total.data_ptr(), len(seeds))
+    halves[1].sync()
+    out = base.cpu().numpy()
+    assert_close(out[:3 * p["T"]].reshape(-1, 3), acc_g, 1e-12, "split average, poses")
+    assert_close(out[3 * p["T"]:].reshape(-1, 2), feat_g, 1e-12, "split average, landmarks")
