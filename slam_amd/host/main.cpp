@@ -161,6 +161,10 @@ int main(int argc, char** argv) try {
   if (multi_mcmc) {
     std::printf("Multi-MCMC-SLAM Chains: %u\n", multi_mcmc->num_chains());
     std::printf("Multi-MCMC-SLAM log likelihood: %.17g\n", multi_mcmc->get_log_likelihood());
+    // main.cpp:315-320 of the reference: the average over the chains and its likelihood
+    const auto average = multi_mcmc->get_average();
+    std::printf("Averaged-Multi-MCMC log likelihood: %.17g\n",
+                slam::slam_log_likelihood<control_model_type, observation_model_type>(*data, *average, cap));
   }
   return 0;
 } catch (const std::exception& e) {

@@ -294,6 +294,23 @@ class multi_mcmc : public slam_result_of<ControlModel, ObservationModel> {
   unsigned int num_chains() const { return chains; }
   double get_log_likelihood() const { return best_ll; }
 
+  // average_slam_result over the chains (multi_mcmc.hpp:71-73): summed on the device, only the
+  // averaged accumulated poses and landmark positions come back; the tree of relative poses is
+  // rebuilt from them as the reference does (average_slam_result.hpp:94-99).
+  std::unique_ptr<slam_result_type> get_average() const {
+    std::uint32_t T = 0, F = 0, C = 0;
+    detail::check(h, mcmcgpu_get_dims(h, &T, &F, &C), "mcmcgpu_get_dims");
+    std::vector<double> cum(3 * std::size_t(T)), world(2 * std::size_t(F));
+    detail::check(h, mcmcgpu_get_average(h, cum.data(), world.data()), "mcmcgpu_get_average");
+    auto result = std::make_unique<slam_result_impl<state_type, feature_type>>();
+    result->get_trajectory().reserve(T);
+    for (std::uint32_t t = 0; t < T; ++t)
+      result->get_trajectory().push_back_accumulated(state_type::cartesian(cum[3 * t], cum[3 * t + 1], cum[3 * t + 2]));
+    for (std::uint32_t f = 0; f < F; ++f)
+      result->get_feature_map()[problem.feature_ids()[f]] = feature_type::cartesian(world[2 * f], world[2 * f + 1]);
+    return result;
+  }
+
   // `count` updates on every chain, then the arg-max (strict >, first maximum wins).
   void update(unsigned int count) {
     detail::check(h, mcmcgpu_run(h, count), "mcmcgpu_run");
@@ -359,6 +376,49 @@ class multi_mcmc : public slam_result_of<ControlModel, ObservationModel> {
 
   mcmcgpu_handle native_handle() const { return h; }
 };
+
+// slam_log_likelihood (src/slam/slam_likelihood.hpp:26-58) of ANY estimate -- the reference calls
+// it on the averaged result and on g2o's (main.cpp:318,326) -- evaluated on the device: the
+// estimate is loaded into a one-chain handle (mcmcgpu_load_state derives the log likelihood from
+// scratch) and read back.  The estimate must cover every timestep and landmark of `data`.
+template <class ControlModel, class ObservationModel>
+double slam_log_likelihood(const slam_data<ControlModel, ObservationModel>& data,
+                           const slam_result_of<ControlModel, ObservationModel>& estimate,
+                           const gpu_capacity& cap = gpu_capacity()) {
+  detail::device_problem<ControlModel, ObservationModel> problem;
+  problem.absorb(data, std::size_t(data.current_timestep()));
+  const auto& trajectory = estimate.get_trajectory();
+  if (trajectory.size() != problem.T()) throw std::runtime_error("slam_log_likelihood: estimate and data differ in length");
+  mcmcgpu_config cfg{};
+  cfg.device = cap.device;
+  cfg.max_chains = 1;
+  cfg.max_timesteps = problem.T();
+  cfg.max_features = problem.F();
+  cfg.max_observations = problem.N();
+  mcmcgpu_handle h = nullptr;
+  if (mcmcgpu_create(&cfg, &h) != 0) throw std::runtime_error(std::string("mcmcgpu_create: ") + mcmcgpu_last_error(nullptr));
+  struct closer {
+    mcmcgpu_handle h;
+    ~closer() { mcmcgpu_destroy(h); }
+  } guard{h};
+  problem.upload(h);
+  const std::uint32_t seed = 0;  // the generator is never drawn from
+  detail::check(h, mcmcgpu_init_chains(h, 1, &seed, nullptr, 0), "mcmcgpu_init_chains");
+  std::vector<double> rel, world;
+  for (std::size_t t = 0; t < trajectory.size(); ++t) {
+    const auto d = trajectory[t];
+    rel.insert(rel.end(), {d.x(), d.y(), d.bearing()});
+  }
+  const auto initial = estimate.get_initial_state();
+  for (const std::size_t id : problem.feature_ids()) {
+    const auto w = -initial + estimate.get_feature(featureid_type(id));
+    world.insert(world.end(), {w.x(), w.y()});
+  }
+  detail::check(h, mcmcgpu_load_state(h, 0, 1, rel.data(), world.data()), "mcmcgpu_load_state");
+  double ll = 0;
+  detail::check(h, mcmcgpu_get_log_likelihood(h, &ll), "mcmcgpu_get_log_likelihood");
+  return ll;
+}
 
 }  // namespace slam
 

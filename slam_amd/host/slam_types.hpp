@@ -158,6 +158,14 @@ class bitree {
   void clear() { node.clear(); }
   void reserve(std::size_t n) { node.reserve(n); }
   void push_back(const G& v) { node.push_back(as_node(node.size(), v)); }
+  // appends the element whose prefix composition accumulate(size()+1) is `total`
+  void push_back_accumulated(const G& total) {
+    const std::size_t n = node.size();
+    if (n == 0)
+      node.push_back(total);
+    else
+      node.push_back(-accumulate(up(n) + 1) + total);
+  }
   G get(std::size_t i) const { return i == 0 ? node[0] : -tail(i - 1, up(i)) + node[i]; }
   G operator[](std::size_t i) const { return get(i); }
   G accumulate(std::size_t b, std::size_t e) const {
@@ -234,6 +242,22 @@ struct slam_result : public data_source {
   virtual feature_type get_feature(featureid_type id) const { return get_feature_map().at(id); }
   virtual const trajectory_type& get_trajectory() const = 0;
   virtual const feature_map_type& get_feature_map() const = 0;
+};
+
+// A result that owns its trajectory and map (slam_result_impl.hpp in the reference).
+template <class State, class Feature>
+class slam_result_impl : public slam_result<State, Feature> {
+  using base = slam_result<State, Feature>;
+  typename base::trajectory_type trajectory;
+  typename base::feature_map_type map;
+
+ public:
+  void timestep(timestep_type) override {}
+  timestep_type current_timestep() const override { return timestep_type(trajectory.size()); }
+  typename base::trajectory_type& get_trajectory() { return trajectory; }
+  typename base::feature_map_type& get_feature_map() { return map; }
+  const typename base::trajectory_type& get_trajectory() const override { return trajectory; }
+  const typename base::feature_map_type& get_feature_map() const override { return map; }
 };
 
 template <class ControlModel, class ObsModel>

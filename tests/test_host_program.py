@@ -5,6 +5,7 @@ import json
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -69,3 +70,5 @@ def test_multi_mcmc_report(tmp_path):
     best = [float(r[2]) for r in rows]
     assert best == sorted(best)  # the best log likelihood never decreases
     assert "Multi-MCMC-SLAM Chains: 8" in out.stdout
+    avg = [ln for ln in out.stdout.splitlines() if ln.startswith("Averaged-Multi-MCMC log likelihood")]
+    assert len(avg) == 1 and np.isfinite(float(avg[0].split()[-1])), out.stdout
