@@ -42,7 +42,7 @@ const char* const kFlags[] = {"dataset", "dataset-dir", "mcmc-slam", "mcmc-steps
                               "multi-mcmc", "multi-mcmc-chains", "multi-mcmc-end-steps", "multi-mcmc-seed", "seed",
                               "init-seed", "sensor-range-stddev", "velmodel-alpha1", "velmodel-alpha2",
                               "velmodel-alpha3", "velmodel-alpha4", "velmodel-alpha5", "velmodel-alpha6",
-                              "dump-loader", "dump-data", "device", "trace-every", "help"};
+                              "dump-loader", "dump-data", "device", "trace-every", "dataset-cache", "help"};
 const char* const kSwitches[] = {"mcmc-slam", "multi-mcmc", "dump-loader", "help"};
 
 options parse(int argc, char** argv) {
@@ -72,7 +72,8 @@ int main(int argc, char** argv) try {
   if (opt.has("help") || !opt.has("dataset")) {
     std::puts("usage: slam_hip --dataset NAME [--dataset-dir DIR] [--mcmc-slam --mcmc-steps N --mcmc-end-steps N]\n"
               "                [--multi-mcmc --multi-mcmc-chains C --multi-mcmc-end-steps N] [--seed S]\n"
-              "                [--sensor-range-stddev X] [--velmodel-alpha1..6 X] [--dump-loader] [--dump-data PREFIX]");
+              "                [--sensor-range-stddev X] [--velmodel-alpha1..6 X] [--dump-loader] [--dump-data PREFIX]\n"
+              "                [--dataset-cache FILE]");
     return opt.has("help") ? 0 : 2;
   }
 
@@ -91,7 +92,15 @@ int main(int argc, char** argv) try {
       opt.num("velmodel-alpha4", 0.01), opt.num("velmodel-alpha5", 0.01 * d * d), opt.num("velmodel-alpha6", 0.001 * d));
   const observation_model_type::builder observation_model_builder(opt.num("sensor-range-stddev", 0.1));
 
-  const auto dataset = slam::read_range_only_data(opt.str("dataset-dir", "input"), opt.str("dataset", ""));
+  // --dataset-cache FILE: load the binary form if it exists, else parse the text logs and leave it behind
+  std::shared_ptr<slam::range_only_dataset> dataset;
+  const std::string cache = opt.str("dataset-cache", "");
+  if (!cache.empty() && std::ifstream(cache, std::ios::binary).good()) {
+    dataset = slam::read_dataset_cache(cache);
+  } else {
+    dataset = slam::read_range_only_data(opt.str("dataset-dir", "input"), opt.str("dataset", ""));
+    if (!cache.empty()) slam::write_dataset_cache(*dataset, cache);
+  }
 
   if (opt.has("dump-loader")) {
     const auto& obs = dataset->observations();

@@ -41,6 +41,44 @@ def test_loader_matches_golden_facts(name):
     assert [float.fromhex(v) for v in kv["sum_ctrl_std"]] == [float.fromhex(v) for v in g["sum_ctrl_std"]]
 
 
+@pytest.mark.parametrize("name", ["Plaza1", "Plaza2"])
+def test_dataset_cache_round_trip(name, tmp_path):
+    """Text logs -> binary cache -> loader: the same dataset, bit for bit, in C++ and in Python."""
+    from slam_amd import dataset_cache
+
+    cache = str(tmp_path / f"{name}.slamro")
+    dump = ("--sensor-range-stddev", "1", "--dump-loader")
+    from_text = run("--dataset", name, "--dataset-dir", PLAZA, *dump)
+    writing = run("--dataset", name, "--dataset-dir", PLAZA, "--dataset-cache", cache, *dump)
+    assert os.path.exists(cache) and writing == from_text
+    from_cache = run("--dataset", name, "--dataset-dir", str(tmp_path / "nowhere"), "--dataset-cache", cache, *dump)
+    assert from_cache == from_text
+    # the Python reader sees what the oracle's text loader sees
+    import oracle_lib
+
+    d = dataset_cache.read(cache)
+    w = oracle_lib.World()
+    w.load_plaza(PLAZA, name, 1.0)
+    inp = w.get_input()
+    assert (d["T"], d["N"]) == w.dims()
+    assert np.array_equal(d["obs_t"], inp["obs_t"]) and np.array_equal(d["obs_id"], inp["obs_id"])
+    assert np.array_equal(d["obs_range"], inp["obs_mean"])
+    assert np.array_equal(d["dt"][:, None] * d["controls"], inp["ctrl_mean"])
+    # and a cache written from Python reads back identically in C++
+    again = str(tmp_path / "again.slamro")
+    dataset_cache.write(again, d["dt"], d["controls"], d["obs_t"], d["obs_id"], d["obs_range"])
+    assert open(again, "rb").read() == open(cache, "rb").read()
+    assert run("--dataset", name, "--dataset-cache", again, *dump) == from_text
+
+
+def test_dataset_cache_rejects_garbage(tmp_path):
+    bad = tmp_path / "bad.slamro"
+    bad.write_bytes(b"not a cache at all" * 8)
+    out = subprocess.run([EXE, "--dataset", "x", "--dataset-cache", str(bad), "--dump-loader"], capture_output=True,
+                         text=True)
+    assert out.returncode == 1 and "not a version-1" in out.stderr
+
+
 def test_unknown_option_is_an_error():
     out = subprocess.run([EXE, "--dataset", "Plaza2", "--no-such-flag"], capture_output=True, text=True)
     assert out.returncode == 1 and "unknown option" in out.stderr
