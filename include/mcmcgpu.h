@@ -50,6 +50,12 @@ typedef struct mcmcgpu_config {
   uint32_t feature_uniform_first;
   uint32_t trace_capacity;    /* MH steps recorded per chain (0 = none) */
   void* stream;               /* hipStream_t to run on; NULL = a stream of its own */
+  /* Observation model (the reference fixes it at compile time, src/main.hpp:22):
+   * 0 = range_only_model (range_bearing_model.hpp:119-196), what the reference
+   * ships with; 1 = range_bearing_model (:21-117), every reading also carries a
+   * bearing (mcmcgpu_set_bearings). */
+  uint32_t range_bearing;
+  uint32_t reserved;          /* 0 */
 } mcmcgpu_config;
 
 /* One Metropolis-Hastings step as recorded when trace_capacity > 0. */
@@ -89,6 +95,14 @@ void mcmcgpu_destroy(mcmcgpu_handle h);
 int mcmcgpu_upload_problem(mcmcgpu_handle h, uint32_t T, const double* ctrl_mean, const double* ctrl_stddev,
                            uint32_t N, const uint32_t* obs_timestep, const uint32_t* obs_feature,
                            const double* obs_mean, const double* obs_stddev, uint32_t F);
+
+/* Range-and-bearing handles only: the bearing half of every reading's model
+ * (range_bearing_model::builder, range_bearing_model.hpp:100-116), in the
+ * ARRIVAL order of the mcmcgpu_upload_problem call it follows; required after
+ * every upload.  A landmark proposal is then inv_observe of two normals
+ * (:84-86), a new landmark starts at inv_observe(mean) without a draw (:93-95),
+ * and the bearing residual is wrapped (:33-36). */
+int mcmcgpu_set_bearings(mcmcgpu_handle h, uint32_t N, const double* bearing_mean, const double* bearing_stddev);
 
 /* Creates C empty chains (timestep 0 not yet processed), chain i seeded like
  * random_source(seeds[i]) (src/utility/random.hpp:24).  init_uniforms, when

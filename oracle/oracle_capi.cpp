@@ -96,6 +96,19 @@ int ora_world_set_input(void* p, std::uint32_t T, const double* cmean, const dou
   return 0;
 }
 
+// Turns the readings given to ora_world_set_input into range-and-bearing observations
+// (range_bearing_model, src/planar_robot/range_bearing_model.hpp:21-117); call before replaying.
+int ora_world_set_bearings(void* p, std::uint32_t N, const double* bearing_mean, const double* bearing_std) {
+  world& w = *static_cast<world*>(p);
+  if (N != w.obs.size() || w.started) return -1;
+  for (std::uint32_t i = 0; i < N; ++i) {
+    w.obs[i].model.bearing = true;
+    w.obs[i].model.mean[1] = bearing_mean[i];
+    w.obs[i].model.stddev[1] = bearing_std[i];
+  }
+  return 0;
+}
+
 // Plaza loader (src/dataset.cpp:17-112) followed by the model builders, as
 // slam_data::add_dataset would apply them.  alphas == NULL -> the defaults of
 // src/planar_robot/velocity_model.cpp:23-32.

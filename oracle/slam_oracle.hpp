@@ -398,48 +398,86 @@ struct velocity_slip_model : independent_normal<3> {
   };
 };
 
-// src/planar_robot/range_bearing_model.hpp:119-196
-struct range_only_model : independent_normal<1> {
-  static constexpr int vector_dim = 1;
-  static double observe(const position& p) { return p.distance(); }  // :135-139
-  // :141-143
-  bool more_accurate_than(const range_only_model& o) const { return std::abs(mean[0]) < std::abs(o.mean[0]); }
+// src/planar_robot/range_bearing_model.hpp -- BOTH landmark observation models in one struct with
+// a run-time switch (the reference picks one at compile time, main.hpp:22): bearing == false is
+// range_only_model (:119-196), the compiled default; bearing == true is range_bearing_model
+// (:21-117).  The normal-distribution arithmetic is independent_normal_base's
+// (src/utility/random.hpp:94-121,230-268) written out for one and for two dimensions.
+struct landmark_model {
+  bool bearing = false;
+  double mean[2] = {0.0, 0.0};    // range, bearing
+  double stddev[2] = {1.0, 1.0};
+  // :141-143 and :70-72
+  bool more_accurate_than(const landmark_model& o) const { return std::abs(mean[0]) < std::abs(o.mean[0]); }
+  // log_likelihood(observe(p)): observe :135-139 / :38-40, subtract :130-133 / :33-36 (bearing
+  // difference wrapped), then random.hpp:103-107,116-121
   double log_likelihood_of(const position& p) const {
-    const double r = observe(p);
-    return log_likelihood(&r);
+    const double log_root_two_pi = 0.5 * std::log(2 * kPi);
+    if (!bearing) {
+      double x = p.distance() - mean[0];
+      x /= stddev[0];
+      const double exponent = -0.5 * (x * x);
+      return exponent - 1 * log_root_two_pi - std::log(stddev[0]);
+    }
+    double x0 = p.distance() - mean[0];
+    double x1 = wrap_angle(p.direction() - mean[1]);
+    x0 /= stddev[0];
+    x1 /= stddev[1];
+    const double exponent = -0.5 * (x0 * x0 + x1 * x1);
+    return exponent - 2 * log_root_two_pi - (std::log(stddev[0]) + std::log(stddev[1]));
   }
-  // proposal_dist :145-176.  The two arguments of position::polar() at :157-158
-  // are unsequenced in the reference; g++ 11 evaluates the uniform first, clang
-  // the normal first.  `uniform_first` selects which.
-  static constexpr int proposal_dim = 2;  // :151
+  // proposal_dist.  Range only (:145-176): polar(N(mu, sigma), U * 2 pi); the two arguments of
+  // position::polar() at :157-158 are unsequenced in the reference; g++ 11 evaluates the uniform
+  // first, clang the normal first.  `uniform_first` selects which.  Range and bearing (:74-96):
+  // inv_observe of a draw from the model, two normals in index order (random.hpp:94-100).
+  static constexpr int proposal_dim = 2;  // :151 (vector_dim + 1) and :80 (vector_dim)
   position propose(random_source& random, bool uniform_first) const {
+    if (bearing) {
+      double v[2];
+      for (int i = 0; i < 2; ++i) v[i] = random.normal();
+      for (int i = 0; i < 2; ++i) v[i] *= stddev[i];
+      for (int i = 0; i < 2; ++i) v[i] += mean[i];
+      return position::polar(v[0], v[1]);
+    }
     double r, u;
     if (uniform_first) {
       u = random.uniform();
-      sample(random, &r);
+      r = random.normal();
+      r *= stddev[0];
+      r += mean[0];
     } else {
-      sample(random, &r);
+      r = random.normal();
+      r *= stddev[0];
+      r += mean[0];
       u = random.uniform();
     }
     return position::polar(r, u * 2 * kPi);
   }
-  double proposal_log_likelihood(const position& x) const {  // :166-169
-    return log_likelihood_of(x) - std::log(2 * kPi);
+  double proposal_log_likelihood(const position& x) const {  // :166-169 / :90-92
+    return bearing ? log_likelihood_of(x) : log_likelihood_of(x) - std::log(2 * kPi);
   }
-  position proposal_initial_value(random_source& random) const {  // :171-175
-    return position::polar(mean[0], random.uniform() * 2 * kPi);
+  position proposal_initial_value(random_source& random) const {  // :171-175 / :93-95 (no draw)
+    return bearing ? position::polar(mean[0], mean[1]) : position::polar(mean[0], random.uniform() * 2 * kPi);
   }
-  struct builder {  // :180-195
-    double stddev;
-    explicit builder(double s) : stddev(s) {}
-    range_only_model operator()(double observation) const {
-      range_only_model m;
-      m.mean[0] = observation;
-      m.stddev[0] = stddev;
+  struct builder {  // :180-195 / :100-116 -- one deviation (pair) for all observations
+    bool bearing;
+    double stddev[2];
+    explicit builder(double range_stddev) : bearing(false), stddev{range_stddev, 1.0} {}
+    builder(double range_stddev, double bearing_stddev) : bearing(true), stddev{range_stddev, bearing_stddev} {}
+    landmark_model operator()(double range, double direction = 0.0) const {
+      landmark_model m;
+      m.bearing = bearing;
+      m.mean[0] = range;
+      m.stddev[0] = stddev[0];
+      if (bearing) {
+        m.mean[1] = direction;
+        m.stddev[1] = stddev[1];
+      }
       return m;
     }
   };
 };
+using range_only_model = landmark_model;  // the name the rest of this file grew up with
 
 // ---------------------------------------------------------------------------
 // Raw dataset: src/slam/dataset_impl.hpp:20-85 (+ interfaces.hpp:130-154)

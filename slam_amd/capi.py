@@ -25,6 +25,8 @@ class Config(ctypes.Structure):
         ("feature_uniform_first", ctypes.c_uint32),
         ("trace_capacity", ctypes.c_uint32),
         ("stream", ctypes.c_void_p),
+        ("range_bearing", ctypes.c_uint32),
+        ("reserved", ctypes.c_uint32),
     ]
 
 
@@ -49,6 +51,7 @@ EXPORTS = [
     "mcmcgpu_create",
     "mcmcgpu_destroy",
     "mcmcgpu_upload_problem",
+    "mcmcgpu_set_bearings",
     "mcmcgpu_init_chains",
     "mcmcgpu_set_initial_estimates",
     "mcmcgpu_advance",
@@ -136,10 +139,10 @@ class McmcGpu:
     """One handle = C chains on one GPU."""
 
     def __init__(self, max_chains, max_timesteps, max_features, max_observations, device=0,
-                 threads_per_chain=0, feature_uniform_first=True, trace_capacity=0, stream=None):
+                 threads_per_chain=0, feature_uniform_first=True, trace_capacity=0, stream=None, range_bearing=False):
         self.lib = load_library()
         cfg = Config(device, max_chains, max_timesteps, max_features, max_observations, threads_per_chain,
-                     1 if feature_uniform_first else 0, trace_capacity, stream)
+                     1 if feature_uniform_first else 0, trace_capacity, stream, 1 if range_bearing else 0, 0)
         self.h = ctypes.c_void_p()
         rc = self.lib.mcmcgpu_create(ctypes.byref(cfg), ctypes.byref(self.h))
         if rc != 0:
@@ -173,6 +176,13 @@ class McmcGpu:
             self.lib.mcmcgpu_upload_problem(self.h, ctypes.c_uint32(cm.shape[0]), _ptr(cm), _ptr(cs),
                                             ctypes.c_uint32(ot.size), _ptr(ot), _ptr(of), _ptr(om), _ptr(os_),
                                             ctypes.c_uint32(F)), "mcmcgpu_upload_problem")
+
+    def set_bearings(self, bearing_mean, bearing_std):
+        """The bearing half of every reading (arrival order); range-and-bearing handles, after every upload."""
+        bm = np.ascontiguousarray(bearing_mean, dtype=np.float64)
+        bs = np.ascontiguousarray(bearing_std, dtype=np.float64)
+        self._check(self.lib.mcmcgpu_set_bearings(self.h, ctypes.c_uint32(bm.size), _ptr(bm), _ptr(bs)),
+                    "mcmcgpu_set_bearings")
 
     def init_chains(self, seeds, init_uniforms=None):
         seeds = np.ascontiguousarray(seeds, dtype=np.uint32)

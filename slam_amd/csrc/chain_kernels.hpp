@@ -62,6 +62,10 @@ struct Dev {
   const double* init_feat;    // [n_init_feat][2] initial landmark estimate relative to its first pose
   uint32_t n_init_rel, n_init_feat;
   double usig_inv;            // 1/sigma when every reading has the same sigma, else 0
+  // range-and-bearing readings (null obear = range only); landmark-major like orec
+  const double* obear;        // [Ncap] measured bearing
+  const double* obsd;         // [Ncap] its std deviation
+  const double* obisd;        // [Ncap] 1 / that
   // ---- chains --------------------------------------------------------------
   uint32_t C, NTcap;
   double *relx, *rely, *relth;  // [C][Tcap]   relative pose of state edge t
@@ -150,6 +154,17 @@ struct Shared {
   uint32_t wcount[kMaxWaves];
   double red[kMaxWaves];
 };
+
+// Separately compiled pieces (see advance_kernel) take the kernel-argument block and the chain's
+// LDS block as address-space-qualified pointers.  A kernel that reaches a piece has its Dev as
+// FIRST parameter, so the argument block starts with it, and reads its Dev THROUGH that block
+// (MG_KERNEL_DEV) -- a by-value parameter whose address is taken would be a private copy, and a
+// piece handed that address as an argument-block pointer would read garbage.
+using DevArgs = const __attribute__((address_space(4))) Dev*;
+using SharedLds = __attribute__((address_space(3))) Shared*;
+#define MG_PIECE __device__ __noinline__
+// only inside a __global__ function whose first parameter is the Dev
+#define MG_KERNEL_DEV(name) const Dev& name = *(const Dev*)(DevArgs)__builtin_amdgcn_kernarg_segment_ptr()
 
 // ---------------------------------------------------------------------------
 // cumulative pose access
@@ -333,7 +348,13 @@ struct RatioStream {
   }
 };
 
+// range-and-bearing readings: a piece of its own, so that its registers are not the range-only
+// stream's problem
+MG_PIECE double piece_ratio_rb(DevArgs dp, SharedLds sp, uint32_t c, uint32_t nseg);
+
 MG_DEV double eval_ratio(const Dev& d, uint32_t c, const Shared& S, uint32_t nseg) {
+  // `d` is the argument block itself here (see MG_KERNEL_DEV), S the chain's LDS block
+  if (d.obear) return piece_ratio_rb((DevArgs)&d, (SharedLds)&S, c, nseg);
   // every reading has the same sigma (what the reference's builder produces) -> no per-reading load of it
   if (d.usig_inv > 0.0) return RatioStream<true>(d, c, S, nseg).run();
   return RatioStream<false>(d, c, S, nseg).run();
@@ -405,6 +426,92 @@ MG_DEV double eval_segments(const Dev& d, uint32_t c, const Shared& S, uint32_t 
     }
   }
   return acc;
+}
+
+// a - 2 pi rint(a / 2 pi): the angle brought into [-pi, pi] (2 pi in two parts, so the reduction
+// of an angle of hundreds of radians keeps its last bits).  The reference's wrap_angle
+// (src/utility/geometry.hpp:8-16) maps to [-pi, pi); the two differ only at +-pi itself, and the
+// residual is squared.
+MG_DEV double wrap_residual(double a) {
+  constexpr double kTwoPiHi = 6.283185307179586232, kTwoPiLo = 2.4492935982947064e-16;
+  const double k = rint(a * (1.0 / kTwoPiHi));
+  return fma(-k, kTwoPiLo, fma(-k, kTwoPiHi, a));
+}
+
+// The same loops for range-AND-bearing readings (range_bearing_model,
+// src/planar_robot/range_bearing_model.hpp:21-117).  Seen from pose s the landmark is at
+// R(-th_s) (w - t_s): its range is |w - t_s| and its bearing atan2(w - t_s) - th_s, so a reading
+// needs the pose's angle too -- per reading 16 B record + 8 B measured bearing + 16 B translation
+// + 8 B angle = 48 bytes.  Residuals: z_r = (r - mu_r) / sigma_r, z_b = wrap(b - mu_b) / sigma_b;
+//   FULL == false:  -(z_r'^2 + z_b'^2) / 2 + (z_r^2 + z_b^2) / 2, each difference of squares as a
+//                   product so that nothing large cancels;
+//   FULL == true :  the log density itself (src/utility/random.hpp:116-121, two dimensions).
+template <bool FULL>
+MG_DEV double eval_segments_rb(const Dev& d, uint32_t c, const Shared& S, uint32_t nseg) {
+  const uint32_t total = S.segpre[nseg];
+  const PoseXY* __restrict__ pxy = d.pxy + size_t(c) * (d.Tcap + 1);
+  const double* __restrict__ pth = d.pth + size_t(c) * (d.Tcap + 1);
+  const ObsRec* __restrict__ orec = d.orec;
+  const double* __restrict__ obear = d.obear;
+  double acc = 0.0;
+  uint32_t cur = 0;
+  constexpr int kUnroll = 2;
+  const uint32_t stride = blockDim.x;
+  for (uint32_t i0 = threadIdx.x; i0 < total; i0 += kUnroll * stride) {
+    uint32_t o[kUnroll], sg[kUnroll];
+    bool ok[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const uint32_t i = i0 + u * stride;
+      ok[u] = i < total;
+      if (ok[u]) {
+        while (i >= S.segpre[cur + 1]) ++cur;
+        o[u] = S.seglo[cur] + (i - S.segpre[cur]);
+      } else {
+        o[u] = S.seglo[0];
+      }
+      sg[u] = cur;
+    }
+    ObsRec rec[kUnroll];
+    double bm[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      rec[u] = orec[o[u]];
+      bm[u] = obear[o[u]];
+    }
+    PoseXY p[kUnroll];
+    double th[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      p[u] = pxy[rec[u].t];
+      th[u] = pth[rec[u].t];
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const double* w = S.segw[sg[u]];
+      const double isd = d.oisd[o[u]], ibsd = d.obisd[o[u]];
+      const double ox = w[0] - p[u].x, oy = w[1] - p[u].y;
+      const double ro = range_of(ox, oy);
+      const double eo = wrap_residual(atan2(oy, ox) - th[u] - bm[u]);
+      double term;
+      if (FULL) {
+        const double zr = (ro - rec[u].mu) * isd, zb = eo * ibsd;
+        term = -0.5 * (zr * zr + zb * zb) - log(2 * kPi) - (log(d.osd[o[u]]) + log(d.obsd[o[u]]));
+      } else {
+        const double nx = w[2] - p[u].x, ny = w[3] - p[u].y;
+        const double rn = range_of(nx, ny);
+        const double en = wrap_residual(atan2(ny, nx) - th[u] - bm[u]);
+        term = (ro - rn) * fma(-2.0, rec[u].mu, ro + rn) * (0.5 * isd * isd) +
+               (eo - en) * (eo + en) * (0.5 * ibsd * ibsd);
+      }
+      if (ok[u]) acc += term;
+    }
+  }
+  return acc;
+}
+
+MG_PIECE double piece_ratio_rb(DevArgs dp, SharedLds sp, uint32_t c, uint32_t nseg) {
+  return eval_segments_rb<false>(*(const Dev*)dp, c, *(const Shared*)sp, nseg);
 }
 
 // Landmark edge (mcmc_slam.hpp:468-474): every reading of landmark f seen so
@@ -568,6 +675,21 @@ MG_DEV void commit_state_edge(const Dev& d, uint32_t c, uint32_t t, const Pose& 
 // ---------------------------------------------------------------------------
 // The driver: lane 0's resumable restatement of mcmc_slam::timestep / update.
 
+MG_DEV Reading load_reading(const Dev& d, uint32_t o) {
+  Reading m;
+  m.mu = d.orec[o].mu;
+  m.sd = d.osd[o];
+  m.bearing = d.obear != nullptr;
+  m.bmu = m.bearing ? d.obear[o] : 0.0;
+  m.bsd = m.bearing ? d.obsd[o] : 1.0;
+  return m;
+}
+
+// proposal_dist::operator() of the reading's model.  Range only
+// (range_bearing_model.hpp:155-159): polar(N(mu, sigma), U 2 pi), draw order by flag.  Range and
+// bearing (:84-86): inv_observe of two normals drawn in index order (random.hpp:94-100).
+MG_DEV Vec2 propose_landmark(const Dev& d, Shared& S, const Reading& m);
+
 MG_DEV void load_control(const Dev& d, uint32_t t, double mu[3], double sd[3]) {
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -592,6 +714,24 @@ MG_DEV void write_trace(const Dev& d, uint32_t c, Shared& S, int kind, uint32_t 
     r.log_likelihood = S.ll;
   }
   d.trace_n[c] = n + 1;
+}
+
+MG_DEV Vec2 propose_landmark(const Dev& d, Shared& S, const Reading& m) {
+  if (m.bearing) {
+    double v0 = rng_normal(S.rng), v1 = rng_normal(S.rng);
+    v0 = v0 * m.sd + m.mu;
+    v1 = v1 * m.bsd + m.bmu;
+    return polar(v0, v1);
+  }
+  double r, u;
+  if (d.uniform_first) {
+    u = rng_uniform(S.rng);
+    r = rng_normal(S.rng) * m.sd + m.mu;
+  } else {
+    r = rng_normal(S.rng) * m.sd + m.mu;
+    u = rng_uniform(S.rng);
+  }
+  return polar(r, u * 2 * kPi);
 }
 
 // mcmc_slam::add_state_edge (mcmc_slam.hpp:227-246) for edge Tcur
@@ -667,19 +807,10 @@ MG_DEV bool driver_begin_update(const Dev& d, uint32_t c, Shared& S) {
       return false;
     }
     const size_t fi = size_t(c) * d.Fcap + f;
-    const uint32_t po = d.foff[f] + d.fpar[fi];
-    const double mu = d.orec[po].mu, sd = d.osd[po];
-    double r, u;
-    if (d.uniform_first) {
-      u = rng_uniform(S.rng);
-      r = rng_normal(S.rng) * sd + mu;
-    } else {
-      r = rng_normal(S.rng) * sd + mu;
-      u = rng_uniform(S.rng);
-    }
-    const Vec2 q = polar(r, u * 2 * kPi);
-    S.new_pll = range_proposal_log_pdf(mu, sd, q);
-    S.old_pll = range_proposal_log_pdf(mu, sd, Vec2{d.fex[fi], d.fey[fi]});
+    const Reading m = load_reading(d, d.foff[f] + d.fpar[fi]);
+    const Vec2 q = propose_landmark(d, S, m);
+    S.new_pll = reading_proposal_log_pdf(m, q);
+    S.old_pll = reading_proposal_log_pdf(m, Vec2{d.fex[fi], d.fey[fi]});
     S.op = OP_EVAL_FEATURE;
     S.idx = f;
     S.q[0] = q.x;
@@ -744,11 +875,14 @@ MG_DEV bool driver_arrival(const Dev& d, uint32_t c, Shared& S, uint32_t o) {
   const uint32_t f = rec.f;
   const size_t fi = size_t(c) * d.Fcap + f;
   const uint32_t t = S.tn;
-  const double mu = rec.mu, sd = d.osd[o];
+  const Reading m = load_reading(d, o);
+  const double mu = rec.mu;
   if (o == d.foff[f]) {  // first reading of this landmark: add_feature_edge, :248-270
     Vec2 est;
     if (f < d.n_init_feat) {  // an initialiser's estimate (:255-258): no draw from the chain
       est = Vec2{d.init_feat[2 * size_t(f)], d.init_feat[2 * size_t(f) + 1]};
+    } else if (m.bearing) {  // proposal_dist::initial_value, range_bearing_model.hpp:93-95: no draw at all
+      est = polar(m.mu, m.bmu);
     } else {
       const double u = (d.init_u && f < d.n_init_u) ? d.init_u[f] : rng_uniform(S.rng);
       est = polar(mu, u * 2 * kPi);
@@ -760,9 +894,9 @@ MG_DEV bool driver_arrival(const Dev& d, uint32_t c, Shared& S, uint32_t o) {
     d.fpt[fi] = t;
     d.flast[fi] = t;
     wt::push_back(d.fw + size_t(c) * d.Fcap, f,
-                  edge_weight_from_log_pdf(range_proposal_log_pdf(mu, sd, est), 2.0, nullptr));
+                  edge_weight_from_log_pdf(reading_proposal_log_pdf(m, est), 2.0, nullptr));
     S.w_dirty = 1;
-    S.ll += range_log_pdf(mu, sd, vec_norm(est));
+    S.ll += reading_log_pdf(m, est);
     S.nf = f + 1;
     return false;
   }
@@ -772,7 +906,7 @@ MG_DEV bool driver_arrival(const Dev& d, uint32_t c, Shared& S, uint32_t o) {
   const uint32_t pt = d.fpt[fi];
   const Vec2 w = act(world_pose(d, c, pt), Vec2{d.fex[fi], d.fey[fi]});
   const Vec2 est = act_inverse(world_pose(d, c, t), w);
-  S.ll += range_log_pdf(mu, sd, vec_norm(est));
+  S.ll += reading_log_pdf(m, est);
   const double par_mu = d.orec[d.foff[f] + d.fpar[fi]].mu;
   if (fabs(mu) < fabs(par_mu)) {  // more_accurate_than, range_bearing_model.hpp:141-143
     d.fpar[fi] = rel;
@@ -780,17 +914,9 @@ MG_DEV bool driver_arrival(const Dev& d, uint32_t c, Shared& S, uint32_t o) {
     d.fex[fi] = est.x;
     d.fey[fi] = est.y;
     // update(feature_edge, false), :320
-    double r, u;
-    if (d.uniform_first) {
-      u = rng_uniform(S.rng);
-      r = rng_normal(S.rng) * sd + mu;
-    } else {
-      r = rng_normal(S.rng) * sd + mu;
-      u = rng_uniform(S.rng);
-    }
-    const Vec2 q = polar(r, u * 2 * kPi);
-    S.new_pll = range_proposal_log_pdf(mu, sd, q);
-    S.old_pll = range_proposal_log_pdf(mu, sd, est);
+    const Vec2 q = propose_landmark(d, S, m);
+    S.new_pll = reading_proposal_log_pdf(m, q);
+    S.old_pll = reading_proposal_log_pdf(m, est);
     S.op = OP_EVAL_FEATURE;
     S.idx = f;
     S.q[0] = q.x;
@@ -935,9 +1061,6 @@ MG_DEV void chain_state_store(const Dev& d, uint32_t c, Shared& S) {
 // argument block and the chain's LDS block as address-space-qualified
 // pointers, so that after inlining inside each piece every access is still a
 // scalar load resp. an LDS operation.
-using DevArgs = const __attribute__((address_space(4))) Dev*;
-using SharedLds = __attribute__((address_space(3))) Shared*;
-#define MG_PIECE __device__ __noinline__
 
 MG_PIECE void piece_driver_advance(DevArgs dp, SharedLds sp, uint32_t c) {
   driver_advance(*(const Dev*)dp, c, *(Shared*)sp);
@@ -972,8 +1095,8 @@ MG_PIECE void piece_finish_update(DevArgs dp, SharedLds sp, uint32_t c, uint32_t
     const uint32_t o = S.rp_obs;
     const size_t fi = size_t(c) * d.Fcap + idx;
     wt::set(d.fw + size_t(c) * d.Fcap, S.nf, idx,
-            edge_weight_from_log_pdf(range_proposal_log_pdf(d.orec[o].mu, d.osd[o], Vec2{d.fex[fi], d.fey[fi]}),
-                                     2.0, nullptr));
+            edge_weight_from_log_pdf(reading_proposal_log_pdf(load_reading(d, o), Vec2{d.fex[fi], d.fey[fi]}), 2.0,
+                                     nullptr));
     S.w_dirty = 1;
   }
   S.pending = PEND_NONE;
@@ -1048,8 +1171,9 @@ __global__ void advance_kernel(Dev d, uint32_t first_tn, uint32_t Tcur0, uint32_
 }
 
 // edge_log_likelihood_ratio for a caller-supplied proposal; grid = 1.
-__global__ void eval_kernel(Dev d, uint32_t c, int kind, uint32_t idx, double q0, double q1, double q2,
+__global__ void eval_kernel(Dev d_by_value, uint32_t c, int kind, uint32_t idx, double q0, double q1, double q2,
                             double* out) {
+  MG_KERNEL_DEV(d);
   __shared__ Shared S;
   unsigned long long units = 0;
   double r;
@@ -1205,7 +1329,7 @@ __global__ void full_ll_kernel(Dev d, uint32_t first, uint32_t Tcur, double* out
     if (tid < nseg) S.segpre[tid + 1] = incl;
     if (tid == 0) S.segpre[0] = 0;
     __syncthreads();
-    acc += eval_segments<true>(d, c, S, nseg);
+    acc += d.obear ? eval_segments_rb<true>(d, c, S, nseg) : eval_segments<true>(d, c, S, nseg);
     __syncthreads();
   }
   const double r = block_sum(acc, S);
@@ -1364,8 +1488,7 @@ __global__ void reweigh_kernel(Dev d, uint32_t first, uint32_t Tcur) {
   const uint32_t nf = d.nf[c];
   for (uint32_t f = threadIdx.x; f < nf; f += blockDim.x) {
     const size_t fi = size_t(c) * d.Fcap + f;
-    const uint32_t po = d.foff[f] + d.fpar[fi];
-    const double lp = range_proposal_log_pdf(d.orec[po].mu, d.osd[po], Vec2{d.fex[fi], d.fey[fi]});
+    const double lp = reading_proposal_log_pdf(load_reading(d, d.foff[f] + d.fpar[fi]), Vec2{d.fex[fi], d.fey[fi]});
     fw[f] = edge_weight_from_log_pdf(lp, 2.0, nullptr);
   }
   build_tree_levels(fw, nf);

@@ -130,6 +130,31 @@ MG_DEV double range_proposal_log_pdf(double mu, double sd, const Vec2& p) {
 
 MG_DEV Vec2 polar(double dist, double dir) { return Vec2{dist * cos(dir), dist * sin(dir)}; }
 
+// ---- one landmark reading as a distribution ----------------------------------
+// Both observation models of src/planar_robot/range_bearing_model.hpp behind a
+// run-time switch: range_only_model (:119-196) and, when `bearing` is set,
+// range_bearing_model (:21-117): observe = (|p|, atan2(y, x)), the bearing
+// residual is wrapped (:33-36), independent normal in both components.
+struct Reading {
+  double mu, sd;    // range
+  double bmu, bsd;  // bearing
+  bool bearing;
+};
+
+// log_likelihood(observe(p)), src/utility/random.hpp:103-121
+MG_DEV double reading_log_pdf(const Reading& m, const Vec2& p) {
+  if (!m.bearing) return range_log_pdf(m.mu, m.sd, vec_norm(p));
+  const double log_root_two_pi = 0.5 * log(2 * kPi);
+  const double x0 = (vec_norm(p) - m.mu) / m.sd;
+  const double x1 = wrap_angle(atan2(p.y, p.x) - m.bmu) / m.bsd;
+  return -0.5 * (x0 * x0 + x1 * x1) - 2 * log_root_two_pi - (log(m.sd) + log(m.bsd));
+}
+
+// proposal_dist::log_likelihood: :166-169 (range only: a uniform direction on top) and :90-92
+MG_DEV double reading_proposal_log_pdf(const Reading& m, const Vec2& p) {
+  return m.bearing ? reading_log_pdf(m, p) : range_log_pdf(m.mu, m.sd, vec_norm(p)) - log(2 * kPi);
+}
+
 MG_DEV double edge_weight_from_log_pdf(double log_pdf, double dim, double* log_weight) {
   const double lw = log(dim) - log_pdf / dim;
   if (log_weight) *log_weight = lw;

@@ -41,6 +41,8 @@ struct mcmcgpu_ctx {
   uint32_t chains = 0;
   bool problem_loaded = false;
   uint32_t next_timestep = 0;  // first timestep the chains have not processed
+  std::vector<uint32_t> h_tobs;        // arrival order -> landmark-major position
+  bool bearings_loaded = false;        // range-and-bearing handles: set_bearings done for the current problem
   std::vector<uint32_t> h_foff, h_ot;  // host copies of the landmark-major index
   std::vector<double> h_omu;
   std::vector<EventPair> timings;
@@ -165,6 +167,11 @@ int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out) {
   ALLOC(d.oisd, d.Ncap);
   ALLOC(d.opiv, size_t(d.Ncap) / 32 + 2);
   ALLOC(d.osd, d.Ncap);
+  if (cfg->range_bearing) {
+    ALLOC(d.obear, d.Ncap);
+    ALLOC(d.obsd, d.Ncap);
+    ALLOC(d.obisd, d.Ncap);
+  }
   ALLOC(d.toff, size_t(d.Tcap) + 2);
   ALLOC(d.tobs, d.Ncap);
   ALLOC(d.ffirst, d.Fcap);
@@ -309,10 +316,37 @@ int mcmcgpu_upload_problem(mcmcgpu_handle h, uint32_t T, const double* ctrl_mean
   d.N = N;
   d.F = F;
   d.usig_inv = uniform_sigma ? 1.0 / obs_stddev[0] : 0.0;
+  h->h_tobs = tobs;
+  h->bearings_loaded = false;
   h->h_foff = foff;
   h->h_ot = ot;
   h->h_omu = omu;
   h->problem_loaded = true;
+  return 0;
+}
+
+int mcmcgpu_set_bearings(mcmcgpu_handle h, uint32_t N, const double* bearing_mean, const double* bearing_stddev) {
+  if (!h || !bearing_mean || !bearing_stddev) return fail(h, MCMCGPU_ERR_ARGUMENT, "null argument");
+  if (!h->cfg.range_bearing) return fail(h, MCMCGPU_ERR_STATE, "the handle was created for range-only readings");
+  if (!h->problem_loaded || N != h->d.N)
+    return fail(h, MCMCGPU_ERR_ARGUMENT, "one bearing per reading of the uploaded problem is required");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  std::vector<double> mu(N), sd(N), isd(N);
+  for (uint32_t i = 0; i < N; ++i) {
+    if (!(bearing_stddev[i] > 0)) return fail(h, MCMCGPU_ERR_ARGUMENT, "non-positive bearing stddev");
+    const uint32_t pos = h->h_tobs[i];
+    mu[pos] = bearing_mean[i];
+    sd[pos] = bearing_stddev[i];
+    isd[pos] = 1.0 / bearing_stddev[i];
+  }
+  const size_t bytes = size_t(N) * sizeof(double);
+  if (N) {
+    HIP_TRY(h, hipMemcpyAsync(const_cast<double*>(h->d.obear), mu.data(), bytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(const_cast<double*>(h->d.obsd), sd.data(), bytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(const_cast<double*>(h->d.obisd), isd.data(), bytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  }
+  h->bearings_loaded = true;
   return 0;
 }
 
@@ -365,6 +399,8 @@ int mcmcgpu_advance(mcmcgpu_handle h, uint32_t upto, uint32_t steps_per_timestep
   if (!h) return MCMCGPU_ERR_ARGUMENT;
   if (!h->problem_loaded || h->chains == 0) return fail(h, MCMCGPU_ERR_STATE, "upload a problem and init chains first");
   if (upto > h->d.T) return fail(h, MCMCGPU_ERR_ARGUMENT, "timestep beyond the uploaded problem");
+  if (h->cfg.range_bearing && !h->bearings_loaded)
+    return fail(h, MCMCGPU_ERR_STATE, "mcmcgpu_set_bearings must follow mcmcgpu_upload_problem on a range-and-bearing handle");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   const bool grow = upto + 1 > h->next_timestep;
   if (!grow && end_steps == 0) return 0;

@@ -60,7 +60,8 @@ def cumulative(rel):
 
 
 def make_problem(T=100_000, n_landmarks=1000, k_nearest=10, seed=12345, dt=0.25, speed=3.0, lap_steps=1250,
-                 turn_wobble=0.5, wobble_period=4000, range_stddev=1.0, landmark_spread=10.0, max_tries=8):
+                 turn_wobble=0.5, wobble_period=4000, range_stddev=1.0, landmark_spread=10.0, max_tries=8,
+                 bearing_stddev=None):
     """A robot circling (with a slow wobble of the turn rate, so laps precess and
     overlap) through a field of landmarks scattered along its path; every
     timestep it ranges the k nearest landmarks.  Landmarks are revisited lap after
@@ -69,7 +70,10 @@ def make_problem(T=100_000, n_landmarks=1000, k_nearest=10, seed=12345, dt=0.25,
 
     Returns a dict with ctrl_mean/ctrl_std [T,3], obs_t/obs_f/obs_mean/obs_std [N]
     (arrival order, N = k_nearest*T, timesteps 0..T-1), F, and the ground truth
-    (true_rel [T,3], true_cum [T+1,3], landmarks [F,2] in dense numbering)."""
+    (true_rel [T,3], true_cum [T+1,3], landmarks [F,2] in dense numbering).  With
+    `bearing_stddev` every reading also carries a bearing (obs_bearing, obs_bearing_std): the
+    landmark's direction in the robot frame plus N(0, bearing_stddev), as the reference's sensor
+    samples a range_bearing_model (src/planar_robot/landmark_sensor.hpp:56-69)."""
     rng = np.random.default_rng(seed)
     t = np.arange(T)
     w0 = 2 * np.pi / (lap_steps * dt)
@@ -107,6 +111,13 @@ def make_problem(T=100_000, n_landmarks=1000, k_nearest=10, seed=12345, dt=0.25,
             break
         landmarks[unseen] = scatter(unseen.size)  # never ranged: move it somewhere else on the path
     obs_mean = obs_true + range_stddev * rng.standard_normal(T * k)
+    extra = {}
+    if bearing_stddev is not None:
+        delta = landmarks[obs_raw] - true_cum[obs_t, :2]
+        direction = np.arctan2(delta[:, 1], delta[:, 0]) - true_cum[obs_t, 2]
+        direction = direction + bearing_stddev * rng.standard_normal(T * k)
+        extra["obs_bearing"] = (direction + np.pi) % (2 * np.pi) - np.pi
+        extra["obs_bearing_std"] = np.full(T * k, bearing_stddev)
 
     # dense landmark numbers in order of first appearance
     _, first_pos = np.unique(obs_raw, return_index=True)
@@ -127,4 +138,5 @@ def make_problem(T=100_000, n_landmarks=1000, k_nearest=10, seed=12345, dt=0.25,
         "true_rel": true_rel,
         "true_cum": true_cum,
         "landmarks": landmarks[order],
+        **extra,
     }

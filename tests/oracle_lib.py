@@ -87,6 +87,12 @@ class World:
                                         _p(ot), _p(oi), _p(om), _p(os_))
         assert rc == 0
 
+    def set_bearings(self, bearing_mean, bearing_std):
+        """Makes every reading of set_input a range-and-bearing observation."""
+        bm = np.ascontiguousarray(bearing_mean, dtype=np.float64)
+        bs = np.ascontiguousarray(bearing_std, dtype=np.float64)
+        assert self.L.ora_world_set_bearings(self.w, ctypes.c_uint32(bm.size), _p(bm), _p(bs)) == 0
+
     def load_plaza(self, directory, name, range_stddev):
         rc = self.L.ora_world_load_plaza(self.w, directory.encode(), name.encode(), ctypes.c_double(range_stddev), None)
         if rc != 0:

@@ -387,3 +387,77 @@ def test_average_over_chains_matches_oracle():
     out = base.cpu().numpy()
     assert_close(out[:3 * p["T"]].reshape(-1, 3), acc_g, 1e-12, "split average, poses")
     assert_close(out[3 * p["T"]:].reshape(-1, 2), feat_g, 1e-12, "split average, landmarks")
+
+
+def _rb_problem(**kw):
+    p = small_problem(**kw)
+    q = synthetic.make_problem(T=p["T"], n_landmarks=p["F"], k_nearest=kw.get("k", 4), seed=kw.get("seed", 3),
+                               lap_steps=150, wobble_period=500, range_stddev=kw.get("range_stddev", 2.0),
+                               landmark_spread=6.0, bearing_stddev=0.05)
+    return q
+
+
+def test_range_bearing_model_matches_oracle():
+    """The reference's other observation model (range_bearing_model): growth, landmark proposals from two
+    normals, wrapped bearing residuals in the ratio and in the from-scratch likelihood."""
+    p = _rb_problem()
+    seeds = capi.seed_sequence(909, 3)
+    steps = 500
+    w = oracle_lib.World()
+    w.set_input(p["ctrl_mean"], p["ctrl_std"], p["obs_t"], p["obs_f"], p["obs_mean"], p["obs_std"])
+    w.set_bearings(p["obs_bearing"], p["obs_bearing_std"])
+    for s in seeds:
+        w.add_chain(int(s), trace=True)
+    w.replay(p["T"])
+    g = capi.McmcGpu(len(seeds), p["T"], p["F"], p["N"], trace_capacity=4096, range_bearing=True)
+    g.upload_problem(p["ctrl_mean"], p["ctrl_std"], p["obs_t"], p["obs_f"], p["obs_mean"], p["obs_std"], p["F"])
+    with pytest.raises(RuntimeError, match="mcmcgpu_set_bearings"):
+        g.init_chains(seeds)
+        g.grow(p["T"])
+    g.set_bearings(p["obs_bearing"], p["obs_bearing_std"])
+    g.init_chains(seeds)
+    g.grow(p["T"])
+    g.sync()
+    ll_grow = g.log_likelihood()
+    for c in range(len(seeds)):
+        assert_close(ll_grow[c], w.log_likelihood(c), REL, f"chain {c} log likelihood after growth")
+    for c in range(len(seeds)):
+        assert w.update(c, steps) >= 0
+    g.run(steps)
+    g.sync()
+    ll, full = g.log_likelihood(), g.full_log_likelihood()
+    for c in range(len(seeds)):
+        compare_traces(g.trace(c), w.trace(c), abs(w.log_likelihood(c)))
+        assert_close(ll[c], w.log_likelihood(c), REL, f"chain {c} final log likelihood")
+        assert_close(full[c], w.full_log_likelihood(c), REL, f"chain {c} full log likelihood")
+        so, sg = w.state(c), g.get_state(c)
+        assert np.array_equal(sg["feat_parent"], so["feat_parent"])
+        assert_close(sg["cum"], so["cum"], REL, "cumulative poses")
+        assert_close(sg["feat_est"], so["feat_est"], REL, "landmark estimates")
+        assert g.counters()[2][c] == w.units(c)
+    # a range-only handle refuses bearings
+    g2 = gpu_handle(p, seeds, trace_capacity=0)
+    with pytest.raises(RuntimeError, match="range-only"):
+        g2.set_bearings(p["obs_bearing"], p["obs_bearing_std"])
+
+
+def test_range_bearing_online_with_updates_matches_oracle():
+    """--mcmc-slam's way with bearings: 5 updates after every timestep (re-parenting updates included)."""
+    p = _rb_problem(T=250, F=10, k=3, seed=13)
+    seeds = capi.seed_sequence(4711, 2)
+    w = oracle_lib.World()
+    w.set_input(p["ctrl_mean"], p["ctrl_std"], p["obs_t"], p["obs_f"], p["obs_mean"], p["obs_std"])
+    w.set_bearings(p["obs_bearing"], p["obs_bearing_std"])
+    for s in seeds:
+        w.add_chain(int(s), steps_per_timestep=5, end_steps=200, trace=True)
+    w.replay(p["T"], finish=True)
+    g = capi.McmcGpu(len(seeds), p["T"], p["F"], p["N"], trace_capacity=4096, range_bearing=True)
+    g.upload_problem(p["ctrl_mean"], p["ctrl_std"], p["obs_t"], p["obs_f"], p["obs_mean"], p["obs_std"], p["F"])
+    g.set_bearings(p["obs_bearing"], p["obs_bearing_std"])
+    g.init_chains(seeds)
+    g.advance(p["T"], steps_per_timestep=5, end_steps=200)
+    g.sync()
+    ll = g.log_likelihood()
+    for c in range(len(seeds)):
+        compare_traces(g.trace(c), w.trace(c), abs(w.log_likelihood(c)))
+        assert_close(ll[c], w.log_likelihood(c), REL, f"chain {c} final log likelihood")

@@ -146,3 +146,21 @@ def test_load_state_is_consistent():
         assert st["feat_parent"][f] == t[np.argmin(mu)]
     assert w.update(c, 300) >= 0
     assert abs(w.log_likelihood(c) - w.full_log_likelihood(c)) <= 1e-9 * abs(w.log_likelihood(c))
+
+
+def test_range_bearing_incremental_equals_full():
+    """The reference's one invariant (incremental log likelihood == slam_log_likelihood) for the
+    range-and-bearing observation model, which the reference's default build does not compile."""
+    from slam_amd import synthetic
+
+    p = synthetic.make_problem(T=200, n_landmarks=8, k_nearest=3, seed=17, lap_steps=150, wobble_period=500,
+                               range_stddev=2.0, landmark_spread=6.0, bearing_stddev=0.05)
+    w = oracle_lib.World()
+    w.set_input(p["ctrl_mean"], p["ctrl_std"], p["obs_t"], p["obs_f"], p["obs_mean"], p["obs_std"])
+    w.set_bearings(p["obs_bearing"], p["obs_bearing_std"])
+    c = w.add_chain(123, steps_per_timestep=3, end_steps=300, trace=True)
+    w.replay(p["T"], finish=True)
+    inc, full = w.log_likelihood(c), w.full_log_likelihood(c)
+    assert abs(inc - full) <= 1e-9 * abs(full), (inc, full)
+    tr = w.trace(c)
+    assert 0 < tr["accepted"].sum() < len(tr)
