@@ -18,6 +18,7 @@
 #include <string>
 
 #include "mcmc_slam_hip.hpp"
+#include "simulator.hpp"
 
 using control_model_type = planar_robot::velocity_slip_model;
 using observation_model_type = planar_robot::range_only_model;
@@ -25,6 +26,9 @@ using slam_data_type = slam::slam_data<control_model_type, observation_model_typ
 using mcmc_slam_type = slam::mcmc_slam<control_model_type, observation_model_type>;
 using multi_mcmc_type = slam::multi_mcmc<control_model_type, observation_model_type>;
 using initialiser_type = slam::slam_initialiser<control_model_type, observation_model_type>;
+using controller_type = planar_robot::waypoint_controller;
+using sensor_type = planar_robot::landmark_sensor;
+using simulator_type = simulator<control_model_type, observation_model_type, controller_type, sensor_type>;
 
 namespace {
 
@@ -42,7 +46,12 @@ const char* const kFlags[] = {"dataset", "dataset-dir", "mcmc-slam", "mcmc-steps
                               "multi-mcmc", "multi-mcmc-chains", "multi-mcmc-end-steps", "multi-mcmc-seed", "seed",
                               "init-seed", "sensor-range-stddev", "velmodel-alpha1", "velmodel-alpha2",
                               "velmodel-alpha3", "velmodel-alpha4", "velmodel-alpha5", "velmodel-alpha6",
-                              "dump-loader", "dump-data", "device", "trace-every", "dataset-cache", "help"};
+                              "dump-loader", "dump-data", "device", "trace-every", "dataset-cache", "help",
+                              // the simulated data source (used when no --dataset is given)
+                              "waypoint-file", "landmark-file", "dt", "sensor-skip", "sim-seed", "waypoint-repetitions",
+                              "waypoint-proximity", "sensor-range-max", "sensor-range-min", "robot-speed",
+                              "robot-max-steering", "robot-max-steering-rate", "controller-paramP",
+                              "controller-paramD", "controller-smoothing"};
 const char* const kSwitches[] = {"mcmc-slam", "multi-mcmc", "dump-loader", "help"};
 
 options parse(int argc, char** argv) {
@@ -69,8 +78,10 @@ options parse(int argc, char** argv) {
 
 int main(int argc, char** argv) try {
   const options opt = parse(argc, argv);
-  if (opt.has("help") || !opt.has("dataset")) {
-    std::puts("usage: slam_hip --dataset NAME [--dataset-dir DIR] [--mcmc-slam --mcmc-steps N --mcmc-end-steps N]\n"
+  if (opt.has("help") || !(opt.has("dataset") || opt.has("waypoint-file") || opt.has("dataset-cache"))) {
+    std::puts("usage: slam_hip (--dataset NAME [--dataset-dir DIR] | --waypoint-file F --landmark-file F [--dt X]\n"
+              "                 [--sensor-skip N] [--sim-seed S] [--waypoint-repetitions X])\n"
+              "                [--mcmc-slam --mcmc-steps N --mcmc-end-steps N]\n"
               "                [--multi-mcmc --multi-mcmc-chains C --multi-mcmc-end-steps N] [--seed S]\n"
               "                [--sensor-range-stddev X] [--velmodel-alpha1..6 X] [--dump-loader] [--dump-data PREFIX]\n"
               "                [--dataset-cache FILE]");
@@ -82,6 +93,7 @@ int main(int argc, char** argv) try {
   const unsigned int seed = opt.has("seed") ? opt.uint("seed", 0) : std::random_device()();
   std::uint32_t draws[6];
   mcmcgpu_seed_sequence(seed, 6, draws);
+  const unsigned int sim_seed = opt.uint("sim-seed", draws[0]);
   const unsigned int init_seed = opt.uint("init-seed", draws[1]);
   const unsigned int mcmc_slam_seed = opt.uint("mcmc-slam-seed", draws[2]);
   const unsigned int multi_mcmc_seed = opt.uint("multi-mcmc-seed", draws[5]);
@@ -97,6 +109,24 @@ int main(int argc, char** argv) try {
   const std::string cache = opt.str("dataset-cache", "");
   if (!cache.empty() && std::ifstream(cache, std::ios::binary).good()) {
     dataset = slam::read_dataset_cache(cache);
+  } else if (!opt.has("dataset")) {  // main.cpp:164-171 of the reference: no data set named -> simulate one
+    controller_type controller;
+    controller.waypoints = planar_robot::read_positions(opt.str("waypoint-file", ""));
+    controller.speed = opt.num("robot-speed", controller.speed);
+    controller.max_steering = opt.num("robot-max-steering", controller.max_steering);
+    controller.max_steering_rate = opt.num("robot-max-steering-rate", controller.max_steering_rate);
+    controller.proximity = opt.num("waypoint-proximity", controller.proximity);
+    controller.repetitions = opt.num("waypoint-repetitions", controller.repetitions);
+    controller.param_P = opt.num("controller-paramP", controller.param_P);
+    controller.param_D = opt.num("controller-paramD", controller.param_D);
+    controller.smoothing = opt.num("controller-smoothing", controller.smoothing);
+    sensor_type sensor;
+    if (opt.has("landmark-file")) sensor.landmarks = planar_robot::read_positions(opt.str("landmark-file", ""));
+    sensor.max_range = opt.num("sensor-range-max", sensor.max_range);
+    sensor.min_range = opt.num("sensor-range-min", sensor.min_range);
+    dataset = std::make_shared<simulator_type>(sim_seed, control_model_builder, observation_model_builder, controller,
+                                               sensor, opt.num("dt", 0.25), opt.uint("sensor-skip", 8));
+    if (!cache.empty()) slam::write_dataset_cache(*dataset, cache);
   } else {
     dataset = slam::read_range_only_data(opt.str("dataset-dir", "input"), opt.str("dataset", ""));
     if (!cache.empty()) slam::write_dataset_cache(*dataset, cache);

@@ -312,26 +312,19 @@ class slam_initialiser : public slam_data<ControlModel, ObservationModel>::liste
   using data_type = slam_data<ControlModel, ObservationModel>;
   using result_type = slam_result_of<ControlModel, ObservationModel>;
   unsigned int m_seed;
-  std::uint32_t m_draws = 0;
+  random_source m_random;
   typename result_type::trajectory_type m_trajectory;
   typename result_type::feature_map_type m_map;
 
-  double next_uniform() {  // draw number m_draws of random_source(seed).uniform()
-    std::vector<double> u(m_draws + 1);
-    mcmcgpu_uniform_sequence(m_seed, m_draws + 1, u.data());
-    return u[m_draws++];
-  }
+  double next_uniform() { return m_random.uniform(); }
 
  public:
-  explicit slam_initialiser(unsigned int seed) : m_seed(seed) {}
+  explicit slam_initialiser(unsigned int seed) : m_seed(seed), m_random(seed) {}
   unsigned int seed() const { return m_seed; }
   void timestep(timestep_type) override {}
   void control(timestep_type, const ControlModel& c) override {
     // inv_observe of the control mean (velocity_model.hpp:51-63, :150-152)
-    const double s = c.mean()(0), alpha = c.mean()(1), beta = c.mean()(2), r = s / alpha;
-    m_trajectory.push_back(std::isfinite(r)
-                               ? planar_robot::pose::cartesian(r * std::sin(alpha), r - r * std::cos(alpha), alpha + beta)
-                               : planar_robot::pose::cartesian(s, 0.0, beta));
+    m_trajectory.push_back(ControlModel::inv_observe(c.mean()));
   }
   void observation(timestep_type t, const typename data_type::observation_info& o) override {
     if (o.index() == 0) {

@@ -16,10 +16,57 @@
 #include <array>
 #include <cmath>
 #include <cstddef>
+#include <cstdint>
 #include <map>
+#include <random>
 #include <vector>
 
+// src/utility/random.hpp:11-42: a std::mt19937 handed, as the generator, to
+// std::uniform_real_distribution<> and std::normal_distribution<>.  The engine is
+// fixed by the C++ standard; the two distributions are libstdc++'s, written out
+// so that the stream does not depend on the standard library in use:
+// generate_canonical<double, 53> takes two engine outputs, (lo + hi 2^32) / 2^64,
+// and steps back below 1 if rounding reached it; the normal distribution is the
+// Marsaglia polar method, which keeps its second variate for the next call.
+class random_source {
+  std::mt19937 engine;
+  bool saved_available = false;
+  double saved = 0.0;
+
+ public:
+  using result_type = std::mt19937::result_type;
+  explicit random_source(unsigned int seed) : engine(seed) {}
+  result_type operator()() { return engine(); }
+  double uniform() {
+    const double lo = double(engine()), hi = double(engine());
+    double r = (lo + hi * 4294967296.0) / 18446744073709551616.0;
+    if (r >= 1.0) r = std::nextafter(1.0, 0.0);
+    return r;
+  }
+  double normal() {
+    if (saved_available) {
+      saved_available = false;
+      return saved;
+    }
+    double x, y, r2;
+    do {
+      x = 2.0 * uniform() - 1.0;
+      y = 2.0 * uniform() - 1.0;
+      r2 = x * x + y * y;
+    } while (r2 > 1.0 || r2 == 0.0);
+    const double mult = std::sqrt(-2 * std::log(r2) / r2);
+    saved = x * mult;
+    saved_available = true;
+    return y * mult;
+  }
+};
+
 namespace planar_robot {
+
+// Sine and cosine of one angle as ONE sincos call, which is what an optimising g++ makes of the
+// pair anyway; glibc's sincos and its sin / cos differ by an ulp now and then, so the pairing is
+// written out instead of left to the inliner.
+inline void sin_cos(double a, double& s, double& c) { ::sincos(a, &s, &c); }
 
 class position {
   double px = 0, py = 0;
@@ -32,7 +79,11 @@ class position {
     p.py = y;
     return p;
   }
-  static position polar(double dist, double dir) { return cartesian(dist * std::cos(dir), dist * std::sin(dir)); }
+  static position polar(double dist, double dir) {
+    double s, c;
+    sin_cos(dir, s, c);
+    return cartesian(dist * c, dist * s);
+  }
   double x() const { return px; }
   double y() const { return py; }
   double distance() const { return std::sqrt(px * px + py * py); }
@@ -55,19 +106,22 @@ class pose {
   double y() const { return py; }
   double bearing() const { return th; }
   pose& operator+=(const pose& o) {  // compose: t += R(th) o.t, angles add unwrapped
-    const double s = std::sin(th), c = std::cos(th);
+    double s, c;
+    sin_cos(th, s, c);
     px += c * o.px - s * o.py;
     py += s * o.px + c * o.py;
     th += o.th;
     return *this;
   }
   pose operator-() const {
-    const double s = std::sin(-th), c = std::cos(-th);
+    double s, c;
+    sin_cos(-th, s, c);
     return cartesian(c * -px - s * -py, s * -px + c * -py, -th);
   }
   friend pose operator+(pose a, const pose& b) { return a += b; }
   friend position operator+(const pose& p, const position& o) {
-    const double s = std::sin(p.th), c = std::cos(p.th);
+    double s, c;
+    sin_cos(p.th, s, c);
     return position::cartesian(p.px + (c * o.x() - s * o.y()), p.py + (s * o.x() + c * o.y()));
   }
 };
@@ -88,9 +142,39 @@ struct independent_normal {
   vector_type m_mean, m_stddev;
   const vector_type& mean() const { return m_mean; }
   const vector_type& stddev() const { return m_stddev; }
+  // a draw: normals in index order, then scaled and shifted (src/utility/random.hpp:94-100)
+  vector_type operator()(random_source& random) const {
+    vector_type r;
+    for (int i = 0; i < N; ++i) r(i) = random.normal();
+    for (int i = 0; i < N; ++i) r(i) *= m_stddev(i);
+    for (int i = 0; i < N; ++i) r(i) += m_mean(i);
+    return r;
+  }
 };
 
 struct velocity_slip_model : independent_normal<3, pose> {
+  // velocity_model.hpp:51-63
+  static pose inv_observe(const vector_type& control) {
+    const double s = control(0), alpha = control(1), beta = control(2), r = s / alpha;
+    if (std::isfinite(r)) {
+      double sa, ca;
+      sin_cos(alpha, sa, ca);
+      return pose::cartesian(r * sa, r - r * ca, alpha + beta);
+    }
+    return pose::cartesian(s, 0.0, beta);
+  }
+  static vector_type from_steering(double s, double alpha, double beta = 0.0) {  // :126-129
+    vector_type v;
+    v(0) = s;
+    v(1) = alpha;
+    v(2) = beta;
+    return v;
+  }
+  struct proposal_dist {  // :131-153
+    const velocity_slip_model& model;
+    pose operator()(random_source& random) const { return inv_observe(model(random)); }
+  };
+  proposal_dist proposal() const { return proposal_dist{*this}; }
   // builder: mean = dt*u, stddev = dt*sqrt((dt*A) u^2)   (velocity_model.hpp:157-181)
   struct builder {
     double A[3][3];
@@ -115,6 +199,11 @@ struct velocity_slip_model : independent_normal<3, pose> {
 };
 
 struct range_only_model : independent_normal<1, position> {
+  static vector_type observe(const position& p) {  // range_bearing_model.hpp:135-139
+    vector_type v;
+    v(0) = p.distance();
+    return v;
+  }
   struct builder {  // range_bearing_model.hpp:180-195
     double stddev;
     explicit builder(double s) : stddev(s) {}
@@ -122,6 +211,28 @@ struct range_only_model : independent_normal<1, position> {
       range_only_model m;
       m.m_mean(0) = observation(0);
       m.m_stddev(0) = stddev;
+      return m;
+    }
+  };
+};
+
+// range_bearing_model.hpp:21-117: range and direction of the landmark in the robot frame
+struct range_bearing_model : independent_normal<2, position> {
+  static vector_type observe(const position& p) {
+    vector_type v;
+    v(0) = p.distance();
+    v(1) = p.direction();
+    return v;
+  }
+  struct builder {  // :100-116
+    double stddev[2];
+    builder(double range_stddev, double bearing_stddev) : stddev{range_stddev, bearing_stddev} {}
+    range_bearing_model operator()(const vector_type& observation) const {
+      range_bearing_model m;
+      for (int i = 0; i < 2; ++i) {
+        m.m_mean(i) = observation(i);
+        m.m_stddev(i) = stddev[i];
+      }
       return m;
     }
   };

@@ -42,7 +42,7 @@ def lib():
         L.ora_chain_trace_size.restype = ctypes.c_uint32
         for name in ("ora_world_dims", "ora_world_get_input", "ora_chain_trace_enable", "ora_chain_trace_get",
                      "ora_chain_dims", "ora_chain_get_state", "ora_chain_get_weight_nodes", "ora_chain_get_rng",
-                     "ora_seed_sequence", "ora_uniform_sequence", "ora_chain_set_beta", "ora_world_average"):
+                     "ora_seed_sequence", "ora_uniform_sequence", "ora_chain_set_beta", "ora_world_average", "ora_world_simulated_truth", "ora_world_get_bearings"):
             getattr(L, name).restype = None
         _lib = L
     return _lib
@@ -92,6 +92,27 @@ class World:
         bm = np.ascontiguousarray(bearing_mean, dtype=np.float64)
         bs = np.ascontiguousarray(bearing_std, dtype=np.float64)
         assert self.L.ora_world_set_bearings(self.w, ctypes.c_uint32(bm.size), _p(bm), _p(bs)) == 0
+
+    def simulate(self, waypoint_file, landmark_file, seed, repetitions=1.0, dt=0.25, sensor_skip=8, range_stddev=0.1,
+                 bearing_stddev=0.0):
+        """The reference's simulator as the data source (range-only unless bearing_stddev > 0)."""
+        rc = self.L.ora_world_simulate(self.w, waypoint_file.encode(), landmark_file.encode(), ctypes.c_uint32(seed),
+                                       ctypes.c_double(repetitions), ctypes.c_double(dt), ctypes.c_uint32(sensor_skip),
+                                       ctypes.c_double(range_stddev), ctypes.c_double(bearing_stddev))
+        if rc != 0:
+            raise RuntimeError(self.L.ora_world_error(self.w).decode())
+
+    def simulated_truth(self):
+        T, _ = self.dims()
+        init, cum = np.empty(3), np.empty((T + 1, 3))
+        self.L.ora_world_simulated_truth(self.w, _p(init), _p(cum))
+        return init, cum
+
+    def get_bearings(self):
+        _, N = self.dims()
+        m, s = np.empty(N), np.empty(N)
+        self.L.ora_world_get_bearings(self.w, _p(m), _p(s))
+        return m, s
 
     def load_plaza(self, directory, name, range_stddev):
         rc = self.L.ora_world_load_plaza(self.w, directory.encode(), name.encode(), ctypes.c_double(range_stddev), None)

@@ -71,6 +71,30 @@ def test_dataset_cache_round_trip(name, tmp_path):
     assert run("--dataset", name, "--dataset-cache", again, *dump) == from_text
 
 
+EXAMPLE = os.path.join(ROOT, "tests", "golden", "example")
+
+
+@pytest.mark.parametrize("seed,repetitions", [(5, 1.0), (77, 2.5)])
+def test_simulator_matches_oracle(seed, repetitions, tmp_path):
+    """The simulated data source (waypoint controller + landmark sensor + simulator loop): the C++
+    host's run equals the oracle's restatement of the reference's, bit for bit."""
+    import oracle_lib
+    from slam_amd import dataset_cache
+
+    wp, lm = os.path.join(EXAMPLE, "waypoints.txt"), os.path.join(EXAMPLE, "landmarks.txt")
+    cache = str(tmp_path / "sim.slamro")
+    run("--waypoint-file", wp, "--landmark-file", lm, "--sim-seed", str(seed), "--waypoint-repetitions",
+        str(repetitions), "--sensor-range-stddev", "1", "--dataset-cache", cache, "--dump-loader")
+    d = dataset_cache.read(cache)
+    w = oracle_lib.World()
+    w.simulate(wp, lm, seed=seed, repetitions=repetitions, range_stddev=1.0)
+    inp = w.get_input()
+    assert (d["T"], d["N"]) == w.dims() and d["T"] > 500 and d["N"] > 100
+    assert np.array_equal(d["obs_t"], inp["obs_t"]) and np.array_equal(d["obs_id"], inp["obs_id"])
+    assert np.array_equal(d["obs_range"], inp["obs_mean"])
+    assert np.array_equal(d["dt"][:, None] * d["controls"], inp["ctrl_mean"])
+
+
 def test_dataset_cache_rejects_garbage(tmp_path):
     bad = tmp_path / "bad.slamro"
     bad.write_bytes(b"not a cache at all" * 8)
@@ -110,3 +134,23 @@ def test_multi_mcmc_report(tmp_path):
     assert "Multi-MCMC-SLAM Chains: 8" in out.stdout
     avg = [ln for ln in out.stdout.splitlines() if ln.startswith("Averaged-Multi-MCMC log likelihood")]
     assert len(avg) == 1 and np.isfinite(float(avg[0].split()[-1])), out.stdout
+
+
+@pytest.mark.gpu
+def test_simulated_run_through_the_drop_in_classes():
+    """No --dataset: the simulator feeds slam_data; --mcmc-slam with the initialiser, 5 updates per timestep and
+    500 at the end; the final log likelihood equals the oracle's run on the oracle's simulation."""
+    import oracle_lib
+
+    wp, lm = os.path.join(EXAMPLE, "waypoints.txt"), os.path.join(EXAMPLE, "landmarks.txt")
+    out = run("--waypoint-file", wp, "--landmark-file", lm, "--mcmc-slam", "--mcmc-steps", "5", "--mcmc-end-steps", "500",
+              "--sensor-range-stddev", "1", "--seed", "9")
+    ll = float([ln for ln in out.splitlines() if ln.startswith("MCMC-SLAM log likelihood")][0].split()[-1])
+    seeds = oracle_lib.seed_sequence(9, 6)  # sim, init, mcmc-slam, hmc, fastslam, multi-mcmc
+    w = oracle_lib.World()
+    w.simulate(wp, lm, seed=int(seeds[0]), range_stddev=1.0)
+    w.set_initialiser(int(seeds[1]))
+    c = w.add_chain(int(seeds[2]), steps_per_timestep=5, end_steps=500, use_initialiser=True)
+    w.replay(w.dims()[0], finish=True)
+    ref = w.log_likelihood(c)
+    assert abs(ll - ref) <= 1e-9 * abs(ref), (ll, ref)
