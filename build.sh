@@ -12,4 +12,7 @@ $HIPCC -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared -std=c++17 -DMG
 # host program: the reference's --mcmc-slam / --multi-mcmc command line over the C ABI
 g++ -O2 -std=c++17 -Wall -Wextra -ffp-contract=off -o slam_amd/host/slam_hip slam_amd/host/main.cpp \
   -Lslam_amd -lmcmcgpu -Wl,-rpath,'$ORIGIN/..'
+# the same program with the reference's other observation model (range and bearing)
+g++ -O2 -std=c++17 -Wall -Wextra -ffp-contract=off -DSLAM_HIP_RANGE_BEARING -o slam_amd/host/slam_hip_rb \
+  slam_amd/host/main.cpp -Lslam_amd -lmcmcgpu -Wl,-rpath,'$ORIGIN/..'
 make -s -C oracle

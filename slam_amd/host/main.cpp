@@ -21,7 +21,13 @@
 #include "simulator.hpp"
 
 using control_model_type = planar_robot::velocity_slip_model;
+// The observation model is a compile-time choice, as in the reference (src/main.hpp:21-22):
+// range only by default, range and bearing with -DSLAM_HIP_RANGE_BEARING (binary slam_hip_rb).
+#ifdef SLAM_HIP_RANGE_BEARING
+using observation_model_type = planar_robot::range_bearing_model;
+#else
 using observation_model_type = planar_robot::range_only_model;
+#endif
 using slam_data_type = slam::slam_data<control_model_type, observation_model_type>;
 using mcmc_slam_type = slam::mcmc_slam<control_model_type, observation_model_type>;
 using multi_mcmc_type = slam::multi_mcmc<control_model_type, observation_model_type>;
@@ -51,7 +57,7 @@ const char* const kFlags[] = {"dataset", "dataset-dir", "mcmc-slam", "mcmc-steps
                               "waypoint-file", "landmark-file", "dt", "sensor-skip", "sim-seed", "waypoint-repetitions",
                               "waypoint-proximity", "sensor-range-max", "sensor-range-min", "robot-speed",
                               "robot-max-steering", "robot-max-steering-rate", "controller-paramP",
-                              "controller-paramD", "controller-smoothing"};
+                              "controller-paramD", "controller-smoothing", "sensor-bearing-stddev"};
 const char* const kSwitches[] = {"mcmc-slam", "multi-mcmc", "dump-loader", "help"};
 
 options parse(int argc, char** argv) {
@@ -102,14 +108,25 @@ int main(int argc, char** argv) try {
   const control_model_type::builder control_model_builder(
       opt.num("velmodel-alpha1", 0.01), opt.num("velmodel-alpha2", 0.0), opt.num("velmodel-alpha3", 1.0 * d * d),
       opt.num("velmodel-alpha4", 0.01), opt.num("velmodel-alpha5", 0.01 * d * d), opt.num("velmodel-alpha6", 0.001 * d));
+#ifdef SLAM_HIP_RANGE_BEARING
+  const observation_model_type::builder observation_model_builder(opt.num("sensor-range-stddev", 0.1),
+                                                                  opt.num("sensor-bearing-stddev", 1.0 * d));
+#else
   const observation_model_type::builder observation_model_builder(opt.num("sensor-range-stddev", 0.1));
+#endif
 
   // --dataset-cache FILE: load the binary form if it exists, else parse the text logs and leave it behind
-  std::shared_ptr<slam::range_only_dataset> dataset;
+  std::shared_ptr<slam::dataset_impl<control_model_type, observation_model_type>> dataset;
   const std::string cache = opt.str("dataset-cache", "");
+#ifdef SLAM_HIP_RANGE_BEARING
+  if (opt.has("dataset") || !cache.empty())
+    throw std::runtime_error("the Plaza logs and the dataset cache hold range-only readings; this binary simulates");
+  {
+#else
   if (!cache.empty() && std::ifstream(cache, std::ios::binary).good()) {
     dataset = slam::read_dataset_cache(cache);
-  } else if (!opt.has("dataset")) {  // main.cpp:164-171 of the reference: no data set named -> simulate one
+  } else if (!opt.has("dataset")) {
+#endif  // main.cpp:164-171 of the reference: no data set named -> simulate one
     controller_type controller;
     controller.waypoints = planar_robot::read_positions(opt.str("waypoint-file", ""));
     controller.speed = opt.num("robot-speed", controller.speed);
@@ -126,10 +143,12 @@ int main(int argc, char** argv) try {
     sensor.min_range = opt.num("sensor-range-min", sensor.min_range);
     dataset = std::make_shared<simulator_type>(sim_seed, control_model_builder, observation_model_builder, controller,
                                                sensor, opt.num("dt", 0.25), opt.uint("sensor-skip", 8));
+#ifndef SLAM_HIP_RANGE_BEARING
     if (!cache.empty()) slam::write_dataset_cache(*dataset, cache);
   } else {
     dataset = slam::read_range_only_data(opt.str("dataset-dir", "input"), opt.str("dataset", ""));
     if (!cache.empty()) slam::write_dataset_cache(*dataset, cache);
+#endif
   }
 
   if (opt.has("dump-loader")) {
@@ -137,8 +156,8 @@ int main(int argc, char** argv) try {
     std::printf("T %zu\nN %zu\n", std::size_t(dataset->current_timestep()), obs.size());
     for (std::size_t i = 0; i < obs.size(); ++i)
       if (i < 5 || i + 5 >= obs.size())
-        std::printf("obs %zu %zu %zu %a\n", i, std::size_t(obs[i].first), std::size_t(obs[i].second.id),
-                    obs[i].second.observation(0));
+        std::printf("obs %zu %zu %zu %a %a\n", i, std::size_t(obs[i].first), std::size_t(obs[i].second.id),
+                    obs[i].second.observation(0), obs[i].second.observation(observation_model_type::vector_dim - 1));
     double sm[3] = {0, 0, 0}, ss[3] = {0, 0, 0};
     for (std::size_t t = 0; t < dataset->current_timestep(); ++t) {
       const auto m = control_model_builder(dataset->control(slam::timestep_type(t)), dataset->timedelta(slam::timestep_type(t)));

@@ -58,12 +58,16 @@ inline void check(mcmcgpu_handle h, int rc, const char* what) {
 template <class ControlModel, class ObservationModel>
 class device_problem {
   using data_type = slam_data<ControlModel, ObservationModel>;
-  std::vector<double> cmean, cstd, omean, ostd;
+  std::vector<double> cmean, cstd, omean, ostd, bmean, bstd;
   std::vector<std::uint32_t> ot, of;
   std::map<std::size_t, std::uint32_t> dense;
   std::vector<std::size_t> ids;  // dense index -> landmark id
 
  public:
+  // range_bearing_model readings carry a second component (range_bearing_model.hpp:21-40)
+  static constexpr bool bearing = ObservationModel::vector_dim == 2;
+  static_assert(ObservationModel::vector_dim == 1 || ObservationModel::vector_dim == 2,
+                "range-only or range-and-bearing observation models");
   std::uint32_t T() const { return std::uint32_t(cmean.size() / 3); }
   std::uint32_t N() const { return std::uint32_t(ot.size()); }
   std::uint32_t F() const { return std::uint32_t(ids.size()); }
@@ -92,6 +96,10 @@ class device_problem {
       of.push_back(ins.first->second);
       omean.push_back(info.observation().mean()(0));
       ostd.push_back(info.observation().stddev()(0));
+      if (bearing) {
+        bmean.push_back(info.observation().mean()(ObservationModel::vector_dim - 1));
+        bstd.push_back(info.observation().stddev()(ObservationModel::vector_dim - 1));
+      }
     }
     return fresh;
   }
@@ -99,6 +107,7 @@ class device_problem {
     check(h, mcmcgpu_upload_problem(h, T(), cmean.data(), cstd.data(), N(), ot.data(), of.data(), omean.data(),
                                     ostd.data(), F()),
           "mcmcgpu_upload_problem");
+    if (bearing) check(h, mcmcgpu_set_bearings(h, N(), bmean.data(), bstd.data()), "mcmcgpu_set_bearings");
   }
 };
 
@@ -137,6 +146,7 @@ class mcmc_slam : public slam_result_of<ControlModel, ObservationModel> {
     cfg.max_features = cap.features;
     cfg.max_observations = cap.observations;
     cfg.feature_uniform_first = cap.feature_uniform_first ? 1 : 0;
+    cfg.range_bearing = decltype(problem)::bearing ? 1 : 0;
     if (mcmcgpu_create(&cfg, &h) != 0) throw std::runtime_error(std::string("mcmcgpu_create: ") + mcmcgpu_last_error(nullptr));
     const std::uint32_t s = seed;
     detail::check(h, mcmcgpu_init_chains(h, 1, &s, nullptr, 0), "mcmcgpu_init_chains");
@@ -282,6 +292,7 @@ class multi_mcmc : public slam_result_of<ControlModel, ObservationModel> {
     cfg.max_features = cap.features;
     cfg.max_observations = cap.observations;
     cfg.feature_uniform_first = cap.feature_uniform_first ? 1 : 0;
+    cfg.range_bearing = decltype(problem)::bearing ? 1 : 0;
     if (mcmcgpu_create(&cfg, &h) != 0) throw std::runtime_error(std::string("mcmcgpu_create: ") + mcmcgpu_last_error(nullptr));
     std::vector<std::uint32_t> seeds(num_chains);
     mcmcgpu_seed_sequence(seed, num_chains, seeds.data());  // successive draws of random_source(seed)
@@ -395,6 +406,7 @@ double slam_log_likelihood(const slam_data<ControlModel, ObservationModel>& data
   cfg.max_timesteps = problem.T();
   cfg.max_features = problem.F();
   cfg.max_observations = problem.N();
+  cfg.range_bearing = decltype(problem)::bearing ? 1 : 0;
   mcmcgpu_handle h = nullptr;
   if (mcmcgpu_create(&cfg, &h) != 0) throw std::runtime_error(std::string("mcmcgpu_create: ") + mcmcgpu_last_error(nullptr));
   struct closer {

@@ -316,7 +316,6 @@ class slam_initialiser : public slam_data<ControlModel, ObservationModel>::liste
   typename result_type::trajectory_type m_trajectory;
   typename result_type::feature_map_type m_map;
 
-  double next_uniform() { return m_random.uniform(); }
 
  public:
   explicit slam_initialiser(unsigned int seed) : m_seed(seed), m_random(seed) {}
@@ -327,11 +326,7 @@ class slam_initialiser : public slam_data<ControlModel, ObservationModel>::liste
     m_trajectory.push_back(ControlModel::inv_observe(c.mean()));
   }
   void observation(timestep_type t, const typename data_type::observation_info& o) override {
-    if (o.index() == 0) {
-      const double pi = 3.14159265358979323846;
-      m_map[o.id()] = this->get_state(t) +
-                      planar_robot::position::polar(o.observation().mean()(0), next_uniform() * 2 * pi);
-    }
+    if (o.index() == 0) m_map[o.id()] = this->get_state(t) + o.observation().initial_value(m_random);
   }
   timestep_type current_timestep() const override { return timestep_type(m_trajectory.size()); }
   const typename result_type::trajectory_type& get_trajectory() const override { return m_trajectory; }

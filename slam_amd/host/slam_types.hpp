@@ -204,6 +204,10 @@ struct range_only_model : independent_normal<1, position> {
     v(0) = p.distance();
     return v;
   }
+  // proposal_dist::initial_value (:171-175): on the measured circle, at a uniformly drawn direction
+  position initial_value(random_source& random) const {
+    return position::polar(m_mean(0), random.uniform() * 2 * 3.14159265358979323846);
+  }
   struct builder {  // range_bearing_model.hpp:180-195
     double stddev;
     explicit builder(double s) : stddev(s) {}
@@ -224,6 +228,8 @@ struct range_bearing_model : independent_normal<2, position> {
     v(1) = p.direction();
     return v;
   }
+  // proposal_dist::initial_value (:93-95): inv_observe of the mean, nothing drawn
+  position initial_value(random_source&) const { return position::polar(m_mean(0), m_mean(1)); }
   struct builder {  // :100-116
     double stddev[2];
     builder(double range_stddev, double bearing_stddev) : stddev{range_stddev, bearing_stddev} {}

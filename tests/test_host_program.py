@@ -10,6 +10,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "slam_amd", "host", "slam_hip")
+EXE_RB = os.path.join(ROOT, "slam_amd", "host", "slam_hip_rb")  # built with the range-and-bearing model
 PLAZA = os.path.join(ROOT, "tests", "golden", "plaza")
 
 
@@ -149,6 +150,52 @@ def test_simulated_run_through_the_drop_in_classes():
     seeds = oracle_lib.seed_sequence(9, 6)  # sim, init, mcmc-slam, hmc, fastslam, multi-mcmc
     w = oracle_lib.World()
     w.simulate(wp, lm, seed=int(seeds[0]), range_stddev=1.0)
+    w.set_initialiser(int(seeds[1]))
+    c = w.add_chain(int(seeds[2]), steps_per_timestep=5, end_steps=500, use_initialiser=True)
+    w.replay(w.dims()[0], finish=True)
+    ref = w.log_likelihood(c)
+    assert abs(ll - ref) <= 1e-9 * abs(ref), (ll, ref)
+
+
+def test_range_bearing_simulator_matches_oracle():
+    """slam_hip_rb (the reference's other compile-time observation model): same simulated readings as the oracle."""
+    import oracle_lib
+
+    wp, lm = os.path.join(EXAMPLE, "waypoints.txt"), os.path.join(EXAMPLE, "landmarks.txt")
+    out = subprocess.run([EXE_RB, "--waypoint-file", wp, "--landmark-file", lm, "--sim-seed", "31", "--sensor-range-stddev",
+                          "1", "--sensor-bearing-stddev", "0.05", "--dump-loader"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    w = oracle_lib.World()
+    w.simulate(wp, lm, seed=31, range_stddev=1.0, bearing_stddev=0.05)
+    inp, (bm, _) = w.get_input(), w.get_bearings()
+    lines = out.stdout.splitlines()
+    kv = {ln.split()[0]: ln.split()[1:] for ln in lines if not ln.startswith("obs")}
+    assert (int(kv["T"][0]), int(kv["N"][0])) == w.dims()
+    rows = [ln.split()[1:] for ln in lines if ln.startswith("obs")]
+    assert len(rows) == 10
+    for i, t, fid, r, b in rows:
+        i = int(i)
+        assert (int(t), int(fid)) == (int(inp["obs_t"][i]), int(inp["obs_id"][i]))
+        assert (float.fromhex(r), float.fromhex(b)) == (float(inp["obs_mean"][i]), float(bm[i]))
+    assert [float.fromhex(v) for v in kv["sum_ctrl_mean"]] == [float(v) for v in inp["ctrl_mean"].sum(axis=0)]
+    err = subprocess.run([EXE_RB, "--dataset", "Plaza1", "--dump-loader"], capture_output=True, text=True)
+    assert err.returncode == 1 and "range-only" in err.stderr
+
+
+@pytest.mark.gpu
+def test_range_bearing_run_through_the_drop_in_classes():
+    """slam::mcmc_slam<velocity_slip_model, range_bearing_model> on the GPU, event by event, against the oracle."""
+    import oracle_lib
+
+    wp, lm = os.path.join(EXAMPLE, "waypoints.txt"), os.path.join(EXAMPLE, "landmarks.txt")
+    out = subprocess.run([EXE_RB, "--waypoint-file", wp, "--landmark-file", lm, "--mcmc-slam", "--mcmc-steps", "5",
+                          "--mcmc-end-steps", "500", "--sensor-range-stddev", "1", "--sensor-bearing-stddev", "0.05",
+                          "--seed", "12"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    ll = float([ln for ln in out.stdout.splitlines() if ln.startswith("MCMC-SLAM log likelihood")][0].split()[-1])
+    seeds = oracle_lib.seed_sequence(12, 6)
+    w = oracle_lib.World()
+    w.simulate(wp, lm, seed=int(seeds[0]), range_stddev=1.0, bearing_stddev=0.05)
     w.set_initialiser(int(seeds[1]))
     c = w.add_chain(int(seeds[2]), steps_per_timestep=5, end_steps=500, use_initialiser=True)
     w.replay(w.dims()[0], finish=True)
