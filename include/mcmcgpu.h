@@ -287,6 +287,11 @@ int mcmcgpu_debug_phase_cycles(mcmcgpu_handle h, uint64_t out[8], int reset);
 int mcmcgpu_selftest_scan(int32_t device, uint32_t n, int32_t p, const int32_t* a, const int32_t* b,
                           int32_t* out_a, int32_t* out_b);
 
+/* Self-test: out[i] = the device's |(dx[i], dy[i])| as the reading stream
+ * computes it (position::distance, src/planar_robot/position.hpp:33, by a
+ * reciprocal-square-root seed and fused refinement steps instead of sqrt). */
+int mcmcgpu_selftest_range(int32_t device, uint32_t n, const double* dx, const double* dy, double* out);
+
 #ifdef __cplusplus
 }
 #endif

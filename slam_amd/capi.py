@@ -85,6 +85,7 @@ EXPORTS = [
     "mcmcgpu_uniform_sequence",
     "mcmcgpu_debug_phase_cycles",
     "mcmcgpu_selftest_scan",
+    "mcmcgpu_selftest_range",
 ]
 
 _lib = None
@@ -119,6 +120,18 @@ def seed_sequence(seed, n):
 def uniform_sequence(seed, n):
     out = np.empty(n, dtype=np.float64)
     load_library().mcmcgpu_uniform_sequence(ctypes.c_uint32(seed), ctypes.c_uint32(n), _ptr(out))
+    return out
+
+
+def selftest_range(dx, dy, device=0):
+    """The device's |(dx, dy)| exactly as the reading stream computes it."""
+    lib = load_library()
+    dx = np.ascontiguousarray(dx, dtype=np.float64)
+    dy = np.ascontiguousarray(dy, dtype=np.float64)
+    out = np.empty(dx.size, dtype=np.float64)
+    rc = lib.mcmcgpu_selftest_range(ctypes.c_int32(device), ctypes.c_uint32(dx.size), _ptr(dx), _ptr(dy), _ptr(out))
+    if rc != 0:
+        raise RuntimeError(f"mcmcgpu_selftest_range failed ({rc}): {lib.mcmcgpu_last_error(None).decode()}")
     return out
 
 

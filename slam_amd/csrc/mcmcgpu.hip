@@ -964,4 +964,26 @@ int mcmcgpu_selftest_scan(int32_t device, uint32_t n, int32_t p, const int32_t* 
   return 0;
 }
 
+int mcmcgpu_selftest_range(int32_t device, uint32_t n, const double* dx, const double* dy, double* out) {
+  if (!dx || !dy || !out || n == 0) return fail(nullptr, MCMCGPU_ERR_ARGUMENT, "bad argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+    return fail(nullptr, MCMCGPU_ERR_HIP, "no such HIP device");
+  mcmcgpu_handle h = nullptr;
+  HIP_TRY(h, hipSetDevice(device));
+  double* buf = nullptr;
+  HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&buf), sizeof(double) * 3 * size_t(n)));
+  hipError_t e = hipMemcpy(buf, dx, sizeof(double) * n, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(buf + n, dy, sizeof(double) * n, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(range_selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, n, buf, buf + n,
+                       buf + 2 * size_t(n));
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(out, buf + 2 * size_t(n), sizeof(double) * n, hipMemcpyDeviceToHost);
+  (void)hipFree(buf);
+  if (e != hipSuccess) return fail(nullptr, MCMCGPU_ERR_HIP, std::string("range self-test: ") + hipGetErrorString(e));
+  return 0;
+}
+
 }  // extern "C"

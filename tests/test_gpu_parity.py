@@ -461,3 +461,19 @@ def test_range_bearing_online_with_updates_matches_oracle():
     for c in range(len(seeds)):
         compare_traces(g.trace(c), w.trace(c), abs(w.log_likelihood(c)))
         assert_close(ll[c], w.log_likelihood(c), REL, f"chain {c} final log likelihood")
+
+
+def test_device_range_is_accurate():
+    """|(dx, dy)| of the reading stream (reciprocal square root + fused refinement) against numpy."""
+    rng = np.random.default_rng(8)
+    n = 200_000
+    mag = 10.0 ** rng.uniform(-6, 5, size=n)
+    ang = rng.uniform(0, 2 * np.pi, size=n)
+    dx, dy = mag * np.cos(ang), mag * np.sin(ang)
+    dx[:4], dy[:4] = [0.0, 3.0, 0.0, 1e-150], [0.0, 4.0, -2.5, 0.0]
+    got = capi.selftest_range(dx, dy)
+    ref = np.hypot(dx, dy)
+    assert got[0] < 1e-139 and got[1] == 5.0 and got[2] == 2.5  # a zero distance stays finite
+    rel = np.abs(got[4:] - ref[4:]) / ref[4:]
+    print("range_of max relative error: %.3e (ulp = 1.1e-16)" % rel.max())
+    assert rel.max() < 4.5e-16

@@ -58,6 +58,9 @@ def main():
         per = cyc[i] / max(nprop, 1)
         print(f"  {NAMES[i]:28s} {100.0 * cyc[i] / busy:6.2f} % of busy   {per:12.0f} cycles per proposal")
     print(f"  reading stream: {cyc[2] / max(units, 1) * 256:.1f} lane-0 cycles per 256 readings")
+    launches = 2  # the warm-up launch was reset away; slot 7 counts the timed launch only after the reset
+    hist = [(int(cyc[7]) >> (16 * k)) & 0xFFFF for k in range(4)]
+    print(f"  driver wavefronts per SIMD id (one per chain and launch): {hist}")
 
 
 if __name__ == "__main__":
