@@ -208,7 +208,7 @@ def test_rebuild_scan_matches_oracle_accumulate():
     assert_close(g.get_state(0)["cum"], grown, 1e-11, "three-pass scan vs poses appended one by one")
 
 
-@pytest.mark.parametrize("threads", [64, 1024])
+@pytest.mark.parametrize("threads", [64, 128, 512, 1024])
 def test_other_workgroup_sizes(threads):
     p = small_problem(T=200, F=9, k=3, seed=13)
     seeds = capi.seed_sequence(1, 2)
