@@ -221,6 +221,21 @@ int mcmcgpu_write_summaries(mcmcgpu_handle h, void* dev_out);
 int mcmcgpu_export_state(mcmcgpu_handle h, uint32_t chain, void* dev_out);
 int mcmcgpu_import_state(mcmcgpu_handle h, uint32_t chain, const void* dev_in, double log_likelihood);
 
+/* Hand-off of one chain's estimate to a CPU consumer WITHOUT stalling the
+ * sampler -- the candidate loop of src/main.cpp:331-337 (10 000 updates, then
+ * g2o_clustering::add(*mcmc_slam), which reads get_trajectory / get_feature_map
+ * through g2o_slam::reinitialise, src/slam/g2o_slam.hpp:270-286, and optimises
+ * on the CPU).  mcmcgpu_snapshot_begin queues, in stream order, a copy of the
+ * chain's relative poses, world landmark positions and log likelihood into a
+ * pinned host buffer of the handle; the caller may queue the next
+ * mcmcgpu_run right behind it.  mcmcgpu_snapshot_wait blocks until THAT copy
+ * has landed (not until the stream is idle) and hands it out: rel_poses
+ * [T][3], feat_world [F'][2]; null pointers are skipped.  One snapshot can be
+ * outstanding per handle. */
+int mcmcgpu_snapshot_begin(mcmcgpu_handle h, uint32_t chain);
+int mcmcgpu_snapshot_wait(mcmcgpu_handle h, uint32_t* timesteps, double* rel_poses, uint32_t* features,
+                          double* feat_world, double* log_likelihood);
+
 /* multi_mcmc::get_average = average_slam_result over the chains
  * (src/slam/multi_mcmc.hpp:71-73, src/slam/average_slam_result.hpp:58-110).
  * What is averaged, packed as doubles: for t < T the accumulated pose

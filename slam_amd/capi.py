@@ -72,6 +72,8 @@ EXPORTS = [
     "mcmcgpu_get_traffic_counters",
     "mcmcgpu_get_trace",
     "mcmcgpu_write_summaries",
+    "mcmcgpu_snapshot_begin",
+    "mcmcgpu_snapshot_wait",
     "mcmcgpu_average_base",
     "mcmcgpu_average_sum",
     "mcmcgpu_average_finish",
@@ -249,6 +251,19 @@ class McmcGpu:
         self._check(self.lib.mcmcgpu_get_ladders(self.h, _ptr(beta), _ptr(slot), _ptr(rll), ctypes.byref(att),
                                                  ctypes.byref(swp)), "mcmcgpu_get_ladders")
         return beta, slot, rll, att.value, swp.value
+
+    def snapshot_begin(self, chain):
+        """Queue a copy of one chain's estimate to pinned host memory; later launches may be queued behind it."""
+        self._check(self.lib.mcmcgpu_snapshot_begin(self.h, ctypes.c_uint32(chain)), "mcmcgpu_snapshot_begin")
+
+    def snapshot_wait(self, max_timesteps, max_features):
+        """(relative poses [T,3], world landmarks [F',2], log likelihood) of the snapshot begun last."""
+        rel = np.empty((max_timesteps, 3), dtype=np.float64)
+        world = np.empty((max_features, 2), dtype=np.float64)
+        T, F, ll = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_double()
+        self._check(self.lib.mcmcgpu_snapshot_wait(self.h, ctypes.byref(T), _ptr(rel), ctypes.byref(F), _ptr(world),
+                                                   ctypes.byref(ll)), "mcmcgpu_snapshot_wait")
+        return rel[:T.value].copy(), world[:F.value].copy(), ll.value
 
     def average_base(self, chain, dev_ptr):
         self._check(self.lib.mcmcgpu_average_base(self.h, ctypes.c_uint32(chain), ctypes.c_void_p(dev_ptr)),

@@ -1302,6 +1302,30 @@ __global__ void readout_kernel(Dev d, uint32_t c, uint32_t Tcur, double* feat_wo
   if (i < Tcur) state_w[i] = wt::get(d.sw + size_t(c) * d.Tcap, i);
 }
 
+// One chain's estimate packed for a hand-off to the host: relative poses [Tcur][3], world landmark
+// positions [nf][2] (get_trajectory / get_feature_map, mcmc_slam.hpp:194-196, :507-525), then the
+// log likelihood and nf as a double.  One thread per pose or landmark.
+__global__ void snapshot_kernel(Dev d, uint32_t c, uint32_t Tcur, double* out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t nf = d.nf[c];
+  if (i < Tcur) {
+    const size_t ri = size_t(c) * d.Tcap + i;
+    out[3 * size_t(i)] = d.relx[ri];
+    out[3 * size_t(i) + 1] = d.rely[ri];
+    out[3 * size_t(i) + 2] = d.relth[ri];
+  }
+  if (i < nf) {
+    const size_t fi = size_t(c) * d.Fcap + i;
+    const Vec2 w = act(world_pose(d, c, d.fpt[fi]), Vec2{d.fex[fi], d.fey[fi]});
+    out[3 * size_t(Tcur) + 2 * size_t(i)] = w.x;
+    out[3 * size_t(Tcur) + 2 * size_t(i) + 1] = w.y;
+  }
+  if (i == 0) {
+    out[3 * size_t(Tcur) + 2 * size_t(nf)] = d.ll[c];
+    out[3 * size_t(Tcur) + 2 * size_t(d.Fcap) + 1] = double(nf);  // fixed place: the host does not know nf yet
+  }
+}
+
 // slam_log_likelihood (src/slam/slam_likelihood.hpp:26-58); grid = chains from `first`.
 // out[c] = the log likelihood from scratch; out_controls[c] (optional) = its control-model part.
 __global__ void full_ll_kernel(Dev d, uint32_t first, uint32_t Tcur, double* out, double* out_controls) {

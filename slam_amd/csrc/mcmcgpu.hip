@@ -47,6 +47,13 @@ struct mcmcgpu_ctx {
   std::vector<double> h_omu;
   std::vector<EventPair> timings;
   std::vector<EventPair> free_events;
+  // hand-off snapshot: device staging, pinned host landing buffer, completion event
+  double* snap_dev = nullptr;
+  double* snap_host = nullptr;
+  size_t snap_doubles = 0;
+  hipEvent_t snap_event = nullptr;
+  bool snap_pending = false;
+  uint32_t snap_T = 0;
   // tempered replicas
   uint32_t ladder = 0;  // replicas per ladder, 0 = no ladders set
   RngState exchange_rng{};
@@ -212,6 +219,13 @@ int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out) {
   if (d.trace_cap) ALLOC(d.trace, C * d.trace_cap);
   ALLOC(h->scan_tot, C * d.NTcap);
   ALLOC(h->seed_stage, C);
+  h->snap_doubles = 3 * size_t(d.Tcap) + 2 * size_t(d.Fcap) + 2;
+  ALLOC(h->snap_dev, h->snap_doubles);
+  if (!rc) {
+    hipError_t he = hipHostMalloc(reinterpret_cast<void**>(&h->snap_host), h->snap_doubles * sizeof(double), 0);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&h->snap_event, hipEventDisableTiming);
+    if (he != hipSuccess) rc = fail(h, MCMCGPU_ERR_HIP, std::string("snapshot buffers: ") + hipGetErrorString(he));
+  }
   h->scratch_doubles = 6 * (size_t(d.Tcap) + 1) + 4 * size_t(d.Fcap) + 16;
   ALLOC(h->scratch, h->scratch_doubles);
 #undef ALLOC
@@ -237,6 +251,8 @@ void mcmcgpu_destroy(mcmcgpu_handle h) {
     (void)hipEventDestroy(ev.start);
     (void)hipEventDestroy(ev.stop);
   }
+  if (h->snap_host) (void)hipHostFree(h->snap_host);
+  if (h->snap_event) (void)hipEventDestroy(h->snap_event);
   for (void* p : h->allocations) (void)hipFree(p);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -750,6 +766,41 @@ int chains_features(mcmcgpu_handle h, uint32_t* nf) {
   return 0;
 }
 }  // namespace
+
+int mcmcgpu_snapshot_begin(mcmcgpu_handle h, uint32_t chain) {
+  if (!h) return MCMCGPU_ERR_ARGUMENT;
+  if (chain >= h->chains) return fail(h, MCMCGPU_ERR_ARGUMENT, "chain out of range");
+  if (h->snap_pending) return fail(h, MCMCGPU_ERR_STATE, "the previous snapshot has not been collected");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  const uint32_t T = edges_grown(h);
+  const uint32_t n = std::max<uint32_t>(std::max(T, h->d.F), 1);
+  hipLaunchKernelGGL(snapshot_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d, chain, T, h->snap_dev);
+  HIP_TRY(h, hipGetLastError());
+  const size_t used = 3 * size_t(T) + 2 * size_t(h->d.Fcap) + 2;  // poses, landmarks, log likelihood, count
+  HIP_TRY(h, hipMemcpyAsync(h->snap_host, h->snap_dev, used * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipEventRecord(h->snap_event, h->stream));
+  h->snap_pending = true;
+  h->snap_T = T;
+  return 0;
+}
+
+int mcmcgpu_snapshot_wait(mcmcgpu_handle h, uint32_t* timesteps, double* rel_poses, uint32_t* features,
+                          double* feat_world, double* log_likelihood) {
+  if (!h) return MCMCGPU_ERR_ARGUMENT;
+  if (!h->snap_pending) return fail(h, MCMCGPU_ERR_STATE, "no snapshot was begun");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  HIP_TRY(h, hipEventSynchronize(h->snap_event));  // only the snapshot: later launches keep running
+  h->snap_pending = false;
+  const size_t T = h->snap_T;
+  const double* s = h->snap_host;
+  const uint32_t nf = uint32_t(s[3 * T + 2 * size_t(h->d.Fcap) + 1]);
+  if (timesteps) *timesteps = uint32_t(T);
+  if (features) *features = nf;
+  if (rel_poses) std::memcpy(rel_poses, s, 3 * T * sizeof(double));
+  if (feat_world) std::memcpy(feat_world, s + 3 * T, 2 * size_t(nf) * sizeof(double));
+  if (log_likelihood) *log_likelihood = s[3 * T + 2 * size_t(nf)];
+  return 0;
+}
 
 int mcmcgpu_average_base(mcmcgpu_handle h, uint32_t chain, void* dev_base) {
   if (!h || !dev_base) return fail(h, MCMCGPU_ERR_ARGUMENT, "null argument");

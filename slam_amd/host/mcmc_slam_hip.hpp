@@ -240,6 +240,30 @@ class mcmc_slam : public slam_result_of<ControlModel, ObservationModel> {
     return map_mirror;
   }
 
+  // The estimate as a result object of its own, fetched without stalling the sampler: begin the
+  // copy, queue more updates behind it, collect it when the CPU consumer is ready for it -- the
+  // candidate loop of the reference's main.cpp:331-337 with the clustering back end running
+  // beside the next batch of updates instead of after it.
+  void snapshot_begin() { detail::check(h, mcmcgpu_snapshot_begin(h, 0), "mcmcgpu_snapshot_begin"); }
+  std::unique_ptr<slam_result_impl<state_type, feature_type>> snapshot_collect(double* log_likelihood = nullptr) {
+    std::vector<double> rel(3 * problem.T()), world(2 * std::size_t(problem.F()));
+    std::uint32_t T = 0, F = 0;
+    detail::check(h, mcmcgpu_snapshot_wait(h, &T, rel.data(), &F, world.data(), log_likelihood), "mcmcgpu_snapshot_wait");
+    auto result = std::make_unique<slam_result_impl<state_type, feature_type>>();
+    result->get_trajectory().reserve(T);
+    for (std::uint32_t t = 0; t < T; ++t)
+      result->get_trajectory().push_back(state_type::cartesian(rel[3 * t], rel[3 * t + 1], rel[3 * t + 2]));
+    for (std::uint32_t f = 0; f < F; ++f)
+      result->get_feature_map()[problem.feature_ids()[f]] = feature_type::cartesian(world[2 * f], world[2 * f + 1]);
+    return result;
+  }
+  // updates queued without waiting for them (update(count) waits, to report the accept count)
+  void update_async(unsigned int count) {
+    if (next_timestep == 0 || count == 0) return;
+    detail::check(h, mcmcgpu_run(h, count), "mcmcgpu_run");
+    invalidate();
+  }
+
   mcmcgpu_handle native_handle() const { return h; }
 
   class updater : public timestep_listener {

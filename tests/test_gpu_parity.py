@@ -477,3 +477,30 @@ def test_device_range_is_accurate():
     rel = np.abs(got[4:] - ref[4:]) / ref[4:]
     print("range_of max relative error: %.3e (ulp = 1.1e-16)" % rel.max())
     assert rel.max() < 4.5e-16
+
+
+def test_snapshot_is_the_state_at_its_place_in_the_stream():
+    """snapshot_begin / snapshot_wait: the estimate as of the point where the snapshot was queued, although more
+    updates were queued behind it before it was collected (the hand-off loop of the reference's main.cpp:331-337)."""
+    p = small_problem()
+    seeds = capi.seed_sequence(61, 2)
+    a, b = gpu_handle(p, seeds, trace_capacity=0), gpu_handle(p, seeds, trace_capacity=0)
+    for g in (a, b):
+        g.grow(p["T"])
+        g.run(300)
+    a.snapshot_begin(1)
+    a.run(300)  # queued behind the snapshot
+    with pytest.raises(RuntimeError, match="has not been collected"):
+        a.snapshot_begin(0)
+    rel, world, ll = a.snapshot_wait(p["T"], p["F"])
+    b.sync()
+    sb = b.get_state(1)
+    assert np.array_equal(rel, sb["rel"]) and np.array_equal(world, sb["feat_world"])
+    assert ll == b.log_likelihood()[1]
+    # the updates queued behind it did run
+    a.sync()
+    b.run(300)
+    b.sync()
+    assert np.array_equal(a.log_likelihood(), b.log_likelihood())
+    with pytest.raises(RuntimeError, match="no snapshot"):
+        a.snapshot_wait(p["T"], p["F"])
