@@ -72,7 +72,7 @@ def parse_args():
     return args
 
 
-def cpu_baseline(problem, seed, target_seconds):
+def cpu_baseline(problem, seed, target_seconds, all_seeds=None):
     """The CPU oracle (restated reference algorithm, one thread, one chain) on a bounded
     sample of the same workload: same problem, same starting state, same chain seed."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -94,13 +94,30 @@ def cpu_baseline(problem, seed, target_seconds):
     w.update(c, n)
     dt = time.perf_counter() - t0
     units = w.units(c) - u0
-    return {
+    out = {
         "value": units / dt,
         "unit": "proposals*observations/s",
         "cores": 1,
         "kind": "port",
         "sample": f"1 chain x {n} updates ({units} units, {dt:.1f} s) from the GPU run's starting state",
     }
+    # the same oracle with one chain per host thread (chains are independent): what the box's cores
+    # give when the reference's serial multi_mcmc loop (multi_mcmc.hpp:109-118) is simply parallelised
+    cores = max(1, min(16, os.cpu_count() or 1))  # a one-GPU box's share of the host is 16 cores
+    if cores > 1 and all_seeds is not None:
+        chains = [c] + [w.add_detached_chain(int(s)) for s in all_seeds[1:cores]]
+        for k in chains[1:]:
+            w.load_state(k, problem["true_rel"], np.arange(problem["F"]), problem["landmarks"])
+        per_chain = max(8, int(n * min(1.0, target_seconds / max(dt, 1e-6))))
+        t0 = time.perf_counter()
+        many = w.update_all(per_chain, nthreads=cores)
+        dt_all = time.perf_counter() - t0
+        out["all_cores"] = {
+            "value": many / dt_all,
+            "cores": cores,
+            "sample": f"{len(chains)} chains x {per_chain} updates on {cores} threads ({many} units, {dt_all:.1f} s)",
+        }
+    return out
 
 
 def plaza1_wall(device, with_cpu):
@@ -290,7 +307,7 @@ def main():
             out["config"]["threads_per_chain"] = args.threads_per_chain
             out["exchange"] = {"attempts": attempts, "swaps": swaps, "chain_at_beta_1": int(slot[0])}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(problem, all_seeds[0], args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(problem, all_seeds[0], args.cpu_seconds, all_seeds)
         if world == 1 and not args.no_plaza:
             g.close()
             out["plaza1"] = plaza1_wall(local_rank, with_cpu=not args.no_cpu_baseline)

@@ -28,6 +28,54 @@ def _summaries(lls, updates, accepts):
     return torch.from_numpy(rec.view(np.float64).reshape(-1, 2).copy())
 
 
+class _HostChains:
+    """Stands in for a GPU handle in the averaging exchange: the three calls of the C ABI
+    (mcmcgpu_average_base / _sum / _finish) restated with numpy on host memory."""
+
+    def __init__(self, vectors, T, F):  # vectors: [chains, 3T + 2F]
+        self.v, self.T, self.F = vectors, T, F
+
+    def dims(self):
+        return self.T, self.F, self.v.shape[0]
+
+    def _view(self, ptr):
+        import ctypes
+        n = 3 * self.T + 2 * self.F
+        return np.ctypeslib.as_array((ctypes.c_double * n).from_address(ptr))
+
+    @staticmethod
+    def _wrap(a):
+        return (a + np.pi) % (2 * np.pi) - np.pi
+
+    def average_base(self, chain, ptr):
+        self._view(ptr)[:] = self.v[chain]
+
+    def average_sum(self, base_ptr, skip, sum_ptr):
+        base, out = self._view(base_ptr), self._view(sum_ptr)
+        out[:] = 0.0
+        angle = np.zeros(base.size, dtype=bool)
+        angle[2:3 * self.T:3] = True
+        for c in range(self.v.shape[0]):
+            if c == skip:
+                continue
+            diff = base - self.v[c]
+            out += np.where(angle, self._wrap(diff), diff)
+
+    def average_finish(self, base_ptr, sum_ptr, n):
+        base, total = self._view(base_ptr), self._view(sum_ptr)
+        angle = np.zeros(base.size, dtype=bool)
+        angle[2:3 * self.T:3] = True
+        res = base - total / n
+        base[:] = np.where(angle, self._wrap(res), res)
+
+
+def _chain_vectors(T, F, chains, seed):
+    rng = np.random.default_rng(seed)
+    v = rng.normal(size=(chains, 3 * T + 2 * F))
+    v[:, 2:3 * T:3] = rng.uniform(-3.1, 3.1, size=(chains, T))  # angles near the wrap on purpose
+    return v
+
+
 def _worker(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -43,8 +91,18 @@ def _worker(rank, world, port, out):
     upd, acc = parallel.counts_of(gathered)
     state = torch.full((6,), float(rank + 1), dtype=torch.float64)
     parallel.broadcast_from_owner(state, owner, world)
+    # per-interval records of one long launch: [intervals, C, 2] -> [intervals, world * C, 2]
+    stacked = torch.stack([local, local + 100.0])
+    wide = parallel.gather_summaries(stacked, world)
+    assert wide.shape == (2, C * world, 2)
+    assert torch.equal(wide[0], gathered) and torch.equal(wide[1], gathered + 100.0)
+    # multi_mcmc::get_average across ranks: base from global chain 0, sums all-reduced
+    T, F = 5, 3
+    vectors = _chain_vectors(T, F, C * world, seed=4)
+    g = _HostChains(vectors[rank * C:(rank + 1) * C].copy(), T, F)
+    acc_avg, feat_avg = parallel.average_over_ranks(g, C, rank, world, torch.device("cpu"))
     out[rank] = (mine.tolist(), gathered[:, 0].tolist(), ll, gid, owner, idx, upd.tolist(), acc.tolist(),
-                 state.tolist())
+                 state.tolist(), acc_avg.numpy().copy(), feat_avg.numpy().copy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -59,7 +117,19 @@ def test_two_ranks_gloo():
     seeds = capi.seed_sequence(99, 8).tolist()
     assert res[0][0] == seeds[:4] and res[1][0] == seeds[4:]  # disjoint blocks of ONE sequence
     for r in (0, 1):
-        _, lls, ll, gid, owner, idx, upd, acc, state = res[r]
+        _, lls, ll, gid, owner, idx, upd, acc, state, acc_avg, feat_avg = res[r]
+        # the average equals the serial accumulator of average_slam_result.hpp:27-54 over all 8 chains
+        T, F = 5, 3
+        vectors = _chain_vectors(T, F, 8, seed=4)
+        one = _HostChains(vectors, T, F)
+        import ctypes
+        base = np.zeros(3 * T + 2 * F)
+        total = np.zeros_like(base)
+        one.average_base(0, base.ctypes.data)
+        one.average_sum(base.ctypes.data, 0, total.ctypes.data)
+        one.average_finish(base.ctypes.data, total.ctypes.data, 8)
+        assert np.allclose(acc_avg.reshape(-1), base[:3 * T], rtol=0, atol=1e-14)
+        assert np.allclose(feat_avg.reshape(-1), base[3 * T:], rtol=0, atol=1e-14)
         assert lls == [-5.0, -3.0, -1.0, -2.0, -4.0, -1.0, -6.0, -7.0]  # global chain order
         assert (ll, gid, owner, idx) == (-1.0, 2, 0, 2)  # tie -> lowest global chain id
         assert upd == [0, 1, 2, 3, 10, 11, 12, 13] and acc == [0, 1, 2, 3, 0, 1, 2, 3]
