@@ -39,9 +39,11 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=["chains", "tempering"], default="chains",
+    ap.add_argument("--workload", choices=["chains", "tempering", "range-bearing"], default="chains",
                     help="chains: BASELINE.json configs[2] (the headline); tempering: configs[4], one ladder of "
-                         "tempered replicas per GPU on a 1M-pose trajectory with a replica exchange after every launch")
+                         "tempered replicas per GPU on a 1M-pose trajectory with a replica exchange after every launch; "
+                         "range-bearing: configs[2] with the reference's other observation model (48 B per unit)")
+    ap.add_argument("--bearing-stddev", type=float, default=0.05, help="range-bearing: sigma of the bearings, rad")
     ap.add_argument("--chains", type=int, default=None, help="chains per GPU (1024; tempering: 64)")
     ap.add_argument("--updates-per-step", type=int, default=None,
                     help="updates per chain per launch (1000; tempering: 200)")
@@ -65,6 +67,8 @@ def parse_args():
         args.updates_per_step = 200 if tempering else 1000
     if args.timesteps is None:
         args.timesteps = 1_000_000 if tempering else 100_000
+    if args.workload == "range-bearing":
+        args.no_cpu_baseline = args.no_plaza = True
     if tempering:
         if args.threads_per_chain == 0:
             args.threads_per_chain = 1024  # few, long chains: the widest workgroup per chain
@@ -173,17 +177,21 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     tempering = args.workload == "tempering"
+    bearing = args.workload == "range-bearing"
     problem = synthetic.make_problem(T=args.timesteps, n_landmarks=args.landmarks, k_nearest=args.k_nearest,
-                                     seed=args.seed, max_tries=2 if tempering else 8)
+                                     seed=args.seed, max_tries=2 if tempering else 8,
+                                     bearing_stddev=args.bearing_stddev if bearing else None)
     T, F, N, C = problem["T"], problem["F"], problem["N"], args.chains
     # one explicit stream for the library's kernels, torch's reductions and the collectives:
     # a zero stream handle would make the library create a private stream of its own
     stream = torch.cuda.Stream(dev)
     torch.cuda.set_stream(stream)
     g = capi.McmcGpu(C, T, F, N, device=local_rank,
-                     threads_per_chain=args.threads_per_chain, stream=stream.cuda_stream)
+                     threads_per_chain=args.threads_per_chain, stream=stream.cuda_stream, range_bearing=bearing)
     g.upload_problem(problem["ctrl_mean"], problem["ctrl_std"], problem["obs_t"], problem["obs_f"],
                      problem["obs_mean"], problem["obs_std"], F)
+    if bearing:
+        g.set_bearings(problem["obs_bearing"], problem["obs_bearing_std"])
     # chain seeds the way multi_mcmc draws them (successive engine outputs), global chain numbering
     all_seeds = capi.seed_sequence(args.seed + 2, C * world)
     g.init_chains(parallel.shard_seeds(all_seeds, C, rank))
@@ -248,17 +256,21 @@ def main():
     elapsed_max = float(t.item())
     units_total, updates_total, accepts_total = (float(x) for x in tot.tolist())
 
+    workload_name = ("synthetic planar robot: %d poses, %d landmarks, %d range readings, %d %s per GPU" %
+                     (T, F, N, C, "tempered replicas (one ladder)" if tempering else
+                      "chains, range-and-bearing readings" if bearing else "chains"))
     if rank == 0:
         traffic = None  # PMC counters cannot be read from inside this process: the last profiling round's figure
         try:
             with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
                 rec = json.load(f)
-            if rec["updates_per_step"] == args.updates_per_step and rec["workload"].endswith(
-                    "%d poses, %d landmarks, %d range readings, %d chains per GPU" % (T, F, N, C)):
+            if rec["updates_per_step"] == args.updates_per_step and rec["workload"] == workload_name:
                 traffic = rec["traffic_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             pass
-        bytes_per_launch = (d_units * BYTES_PER_UNIT + d_state * F * BYTES_PER_LANDMARK +
+        # a range-and-bearing reading also needs the pose's angle and the measured bearing: 48 bytes
+        unit_bytes = BYTES_PER_UNIT + 16 if bearing else BYTES_PER_UNIT
+        bytes_per_launch = (d_units * unit_bytes + d_state * F * BYTES_PER_LANDMARK +
                             d_moved * BYTES_PER_MOVED_POSE) / max(launches, 1)
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         out = {
@@ -275,8 +287,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "synthetic planar robot: %d poses, %d landmarks, %d range readings, %d %s per GPU" %
-                            (T, F, N, C, "tempered replicas (one ladder)" if tempering else "chains"),
+                "workload": workload_name,
                 "chains_total": C * world,
                 "updates_per_step": args.updates_per_step,
                 "report_every": args.report_every,
