@@ -139,8 +139,14 @@ int mcmcgpu_run(mcmcgpu_handle h, uint32_t steps);
  * mcmcgpu_chain_summary to DEVICE memory dev_out[interval * C + chain];
  * ceil(steps / report_every) intervals.  Chains cost different amounts of work
  * per update, so a launch lasts as long as its slowest chain; long launches
- * keep the idle tail small without giving up the report cadence. */
+ * keep the idle tail small without giving up the report cadence.
+ * dev_out == NULL: the records go to a buffer of the library (at most 256
+ * intervals per launch) and mcmcgpu_get_reports copies them to HOST memory,
+ * out[interval * C + chain], after the launch has finished; *intervals = how
+ * many there are (out may be NULL to ask only that). */
 int mcmcgpu_run_reported(mcmcgpu_handle h, uint32_t steps, uint32_t report_every, void* dev_out);
+int mcmcgpu_get_reports(mcmcgpu_handle h, mcmcgpu_chain_summary* out, uint32_t capacity_intervals,
+                        uint32_t* intervals);
 
 /* Parallel tempering.  NO counterpart in the reference (its sampler is the
  * case beta = 1); this is the "tempered replicas" batching mode.  The chains

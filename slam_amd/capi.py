@@ -58,6 +58,7 @@ EXPORTS = [
     "mcmcgpu_grow",
     "mcmcgpu_run",
     "mcmcgpu_run_reported",
+    "mcmcgpu_get_reports",
     "mcmcgpu_set_ladders",
     "mcmcgpu_exchange",
     "mcmcgpu_get_ladders",
@@ -230,7 +231,16 @@ class McmcGpu:
         """`steps` updates per chain in one launch; summaries [ceil(steps/report_every)][C] to device memory."""
         self._check(
             self.lib.mcmcgpu_run_reported(self.h, ctypes.c_uint32(steps), ctypes.c_uint32(report_every),
-                                          ctypes.c_void_p(dev_ptr)), "mcmcgpu_run_reported")
+                                          ctypes.c_void_p(dev_ptr) if dev_ptr else None), "mcmcgpu_run_reported")
+
+    def get_reports(self):
+        """Records of the last run_reported(..., dev_ptr=None): structured array [intervals, C]."""
+        n = ctypes.c_uint32()
+        self._check(self.lib.mcmcgpu_get_reports(self.h, None, ctypes.c_uint32(0), ctypes.byref(n)), "mcmcgpu_get_reports")
+        out = np.zeros((n.value, self.chains), dtype=CHAIN_SUMMARY)
+        self._check(self.lib.mcmcgpu_get_reports(self.h, _ptr(out), ctypes.c_uint32(n.value), ctypes.byref(n)),
+                    "mcmcgpu_get_reports")
+        return out
 
     def set_ladders(self, betas, exchange_seed):
         """Tempered replicas: ladders of len(betas) consecutive chains, slot s at inverse temperature betas[s]."""

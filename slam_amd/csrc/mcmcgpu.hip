@@ -47,6 +47,9 @@ struct mcmcgpu_ctx {
   std::vector<double> h_omu;
   std::vector<EventPair> timings;
   std::vector<EventPair> free_events;
+  // report records of the last mcmcgpu_run_reported that used the library's own buffer
+  mcmcgpu_chain_summary* reports = nullptr;  // [kMaxOwnReports][max_chains]
+  uint32_t report_intervals = 0;
   // hand-off snapshot: device staging, pinned host landing buffer, completion event
   double* snap_dev = nullptr;
   double* snap_host = nullptr;
@@ -94,6 +97,8 @@ int dev_alloc(mcmcgpu_handle h, T** out, size_t count) {
 }
 
 uint32_t edges_grown(const mcmcgpu_ctx* h) { return h->next_timestep == 0 ? 0 : h->next_timestep - 1; }
+
+constexpr uint32_t kMaxOwnReports = 256;  // intervals of one launch the library can hold itself
 
 bool is_pow2(uint32_t v) { return v && !(v & (v - 1)); }
 
@@ -219,6 +224,7 @@ int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out) {
   if (d.trace_cap) ALLOC(d.trace, C * d.trace_cap);
   ALLOC(h->scan_tot, C * d.NTcap);
   ALLOC(h->seed_stage, C);
+  ALLOC(h->reports, size_t(kMaxOwnReports) * C);
   h->snap_doubles = 3 * size_t(d.Tcap) + 2 * size_t(d.Fcap) + 2;
   ALLOC(h->snap_dev, h->snap_doubles);
   if (!rc) {
@@ -448,7 +454,15 @@ int mcmcgpu_run(mcmcgpu_handle h, uint32_t steps) {
 
 int mcmcgpu_run_reported(mcmcgpu_handle h, uint32_t steps, uint32_t report_every, void* dev_out) {
   if (!h) return MCMCGPU_ERR_ARGUMENT;
-  if (!dev_out || report_every == 0) return fail(h, MCMCGPU_ERR_ARGUMENT, "report buffer and interval are required");
+  if (report_every == 0) return fail(h, MCMCGPU_ERR_ARGUMENT, "the report interval must be positive");
+  const uint32_t intervals = (steps + report_every - 1) / report_every;
+  if (!dev_out) {  // the library's own buffer, read back with mcmcgpu_get_reports
+    if (intervals > kMaxOwnReports)
+      return fail(h, MCMCGPU_ERR_CAPACITY, "more report intervals than the library's buffer holds (" +
+                                               std::to_string(kMaxOwnReports) + "); pass a buffer or split the run");
+    dev_out = h->reports;
+    h->report_intervals = intervals;
+  }
   h->d.snap_out = static_cast<mcmcgpu_chain_summary*>(dev_out);
   h->d.snap_every = report_every;
   const int rc = mcmcgpu_run(h, steps);
@@ -522,6 +536,18 @@ int mcmcgpu_get_ladders(mcmcgpu_handle h, double* beta, uint32_t* slot_chain, do
   if (attempts) *attempts = counts[0];
   if (swaps) *swaps = counts[1];
   return 0;
+}
+
+int mcmcgpu_get_reports(mcmcgpu_handle h, mcmcgpu_chain_summary* out, uint32_t capacity, uint32_t* intervals) {
+  if (!h || !intervals) return fail(h, MCMCGPU_ERR_ARGUMENT, "null argument");
+  *intervals = h->report_intervals;
+  if (!out) return 0;
+  if (capacity < h->report_intervals) return fail(h, MCMCGPU_ERR_CAPACITY, "report array too small");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  const size_t n = size_t(h->report_intervals) * h->chains;
+  if (n) HIP_TRY(h, hipMemcpyAsync(out, h->reports, n * sizeof(mcmcgpu_chain_summary), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return check_device_flags(h);
 }
 
 int mcmcgpu_eval_llr(mcmcgpu_handle h, uint32_t chain, int kind, uint32_t index, const double proposed[3],

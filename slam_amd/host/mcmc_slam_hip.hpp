@@ -23,6 +23,7 @@
 #ifndef SLAM_AMD_HOST_MCMC_SLAM_HIP_HPP
 #define SLAM_AMD_HOST_MCMC_SLAM_HIP_HPP
 
+#include <algorithm>
 #include <cstdint>
 #include <fstream>
 #include <map>
@@ -300,6 +301,26 @@ class multi_mcmc : public slam_result_of<ControlModel, ObservationModel> {
   std::size_t next_timestep = 0;
   unsigned int max_likelihood = 0;  // index of the best chain
   double best_ll = 0;
+  std::vector<double> chain_ll;     // every chain's log likelihood after its latest round of updates
+
+  // The comparison loop of multi_mcmc::update (multi_mcmc.hpp:109-118) for one round.  The
+  // reference steps chain after chain and compares each, right after ITS updates, with the current
+  // best chain -- whose own updates of this round have only happened if it comes earlier in the
+  // order.  `after` holds every chain's log likelihood at the end of the round, chain_ll the values
+  // of the round before.
+  void ensure_baseline() {  // the log likelihoods the chains have before their first round
+    if (!chain_ll.empty()) return;
+    chain_ll.resize(chains);
+    detail::check(h, mcmcgpu_get_log_likelihood(h, chain_ll.data()), "mcmcgpu_get_log_likelihood");
+  }
+  void compare_round(const double* after) {
+    for (unsigned int c = 0; c < chains; ++c) {
+      const double best_now = max_likelihood < c ? after[max_likelihood] : chain_ll[max_likelihood];
+      if (after[c] > best_now) max_likelihood = c;
+    }
+    chain_ll.assign(after, after + chains);
+    best_ll = chain_ll[max_likelihood];
+  }
   std::string report_path;
   mutable trajectory_type trajectory_mirror;
   mutable feature_map_type map_mirror;
@@ -348,12 +369,11 @@ class multi_mcmc : public slam_result_of<ControlModel, ObservationModel> {
 
   // `count` updates on every chain, then the arg-max (strict >, first maximum wins).
   void update(unsigned int count) {
+    ensure_baseline();
     detail::check(h, mcmcgpu_run(h, count), "mcmcgpu_run");
     std::vector<double> ll(chains);
     detail::check(h, mcmcgpu_get_log_likelihood(h, ll.data()), "mcmcgpu_get_log_likelihood");
-    for (unsigned int c = 0; c < chains; ++c)
-      if (ll[c] > ll[max_likelihood]) max_likelihood = c;
-    best_ll = ll[max_likelihood];
+    compare_round(ll.data());
   }
 
   void timestep(timestep_type t) override {
@@ -364,23 +384,36 @@ class multi_mcmc : public slam_result_of<ControlModel, ObservationModel> {
     next_timestep = std::size_t(t) + 1;
   }
 
-  // End steps in report intervals of 100, one report line each.
+  // End steps with a report line after every 100 updates (multi_mcmc.hpp:121-139).  The chains
+  // run up to 256 report intervals per launch and leave one record per chain and interval behind
+  // (mcmcgpu_run_reported); the lines, and the best chain after every interval, are derived from
+  // those records exactly as the reference's round-by-round loop would have.
   void completed() override {
     std::ofstream report(report_path);
     unsigned int remaining = mcmc_end_steps;
-    const unsigned int report_every = 100;
+    const unsigned int report_every = 100, max_intervals = 256;
+    std::vector<mcmcgpu_chain_summary> rec;
+    std::vector<double> after(chains);
+    ensure_baseline();
     while (remaining > 0) {
-      const unsigned int n = remaining > report_every ? report_every : remaining;
-      update(n);
+      const unsigned int n = std::min(remaining, report_every * max_intervals);
       remaining -= n;
-      std::vector<std::uint64_t> upd(chains), acc(chains);
-      detail::check(h, mcmcgpu_get_counters(h, upd.data(), acc.data(), nullptr), "mcmcgpu_get_counters");
-      std::uint64_t u = 0, a = 0;
-      for (unsigned int c = 0; c < chains; ++c) {
-        u += upd[c];
-        a += acc[c];
+      detail::check(h, mcmcgpu_run_reported(h, n, report_every, nullptr), "mcmcgpu_run_reported");
+      std::uint32_t intervals = 0;
+      detail::check(h, mcmcgpu_get_reports(h, nullptr, 0, &intervals), "mcmcgpu_get_reports");
+      rec.resize(std::size_t(intervals) * chains);
+      detail::check(h, mcmcgpu_get_reports(h, rec.data(), intervals, &intervals), "mcmcgpu_get_reports");
+      for (std::uint32_t k = 0; k < intervals; ++k) {
+        std::uint64_t u = 0, a = 0;
+        for (unsigned int c = 0; c < chains; ++c) {
+          const mcmcgpu_chain_summary& r = rec[std::size_t(k) * chains + c];
+          after[c] = r.log_likelihood;
+          u += r.updates;
+          a += r.accepts;
+        }
+        compare_round(after.data());
+        report << (double(u) / chains) << '\t' << (double(a) / chains) << '\t' << get_log_likelihood() << '\n';
       }
-      report << (double(u) / chains) << '\t' << (double(a) / chains) << '\t' << get_log_likelihood() << '\n';
     }
   }
 

@@ -133,6 +133,29 @@ def test_multi_mcmc_report(tmp_path):
     best = [float(r[2]) for r in rows]
     assert best == sorted(best)  # the best log likelihood never decreases
     assert "Multi-MCMC-SLAM Chains: 8" in out.stdout
+    # the report lines against the reference's loop (multi_mcmc.hpp:106-139) played with the oracle: chain after
+    # chain, each compared right after ITS updates with the best chain so far
+    import oracle_lib
+
+    seeds = oracle_lib.seed_sequence(int(oracle_lib.seed_sequence(7, 6)[5]), 8)
+    w = oracle_lib.World()
+    w.load_plaza(PLAZA, "Plaza2", 4.0)
+    for s in seeds:
+        w.add_chain(int(s))
+    w.replay(w.dims()[0])
+    best, updates, accepted = 0, 0, 0
+    for k, n in enumerate([100, 100, 50]):
+        for c in range(8):
+            acc = w.update(c, n)
+            assert acc >= 0
+            accepted += acc
+            updates += n
+            if w.log_likelihood(c) > w.log_likelihood(best):
+                best = c
+        assert float(rows[k][0]) == updates / 8
+        assert abs(float(rows[k][1]) - accepted / 8) < 1e-4  # printed with six significant digits
+        ref = w.log_likelihood(best)
+        assert abs(float(rows[k][2]) - ref) <= 2e-6 * abs(ref), (k, rows[k][2], ref)
     avg = [ln for ln in out.stdout.splitlines() if ln.startswith("Averaged-Multi-MCMC log likelihood")]
     assert len(avg) == 1 and np.isfinite(float(avg[0].split()[-1])), out.stdout
 
