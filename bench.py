@@ -59,6 +59,9 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-plaza", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="testing aid: all ranks share GPU 0 and exchange over gloo (RCCL refuses two ranks on one "
+                         "device); exercises the N > 1 code path on a one-GPU box, its numbers mean nothing")
     args = ap.parse_args()
     tempering = args.workload == "tempering"
     if args.chains is None:
@@ -171,10 +174,15 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     tempering = args.workload == "tempering"
     bearing = args.workload == "range-bearing"
@@ -220,8 +228,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def note(msg):  # progress lines for rehearsals, where a hang must be located from a log
+        if args.rehearse_on_one_gpu:
+            print(f"[rank {rank}] {msg}", file=sys.stderr, flush=True)
+
+    note("problem uploaded, chains loaded")
     for i in range(args.warmup):
         one_step(i)
+        note(f"warm-up step {i} done")
     barrier()
     g.kernel_time()  # reset the library's kernel timer
     u0 = g.counters()
@@ -232,6 +246,7 @@ def main():
         gathered, ll = one_step(args.warmup + i)
     barrier()
     elapsed = time.perf_counter() - t0
+    note("timed steps done")
     # a result is asked for: arg-max with multi_mcmc's tie rule, then the winner's state from its owner
     best["ll"], best["chain"], owner, owner_idx = parallel.best_chain(gathered, C)
     packed = torch.zeros(3 * T + 2 * F, dtype=torch.float64, device=dev)
@@ -250,9 +265,8 @@ def main():
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     tot = torch.tensor([d_units, d_updates, d_accepts], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    parallel.all_reduce(t, dist.ReduceOp.MAX, world)
+    parallel.all_reduce(tot, dist.ReduceOp.SUM, world)
     elapsed_max = float(t.item())
     units_total, updates_total, accepts_total = (float(x) for x in tot.tolist())
 

@@ -13,6 +13,12 @@ import torch
 import torch.distributed as dist
 
 
+def _host_staged(group=None):
+    """gloo moves host memory only; device tensors are staged through the host for it (the CPU
+    tests, and rehearsals of the multi-rank path on one GPU).  RCCL takes device memory as is."""
+    return dist.is_initialized() and dist.get_backend(group) == "gloo"
+
+
 def shard_range(chains_per_rank, rank):
     """Global chain ids owned by `rank`: a contiguous block, GPU g owns [g*C, (g+1)*C)."""
     return rank * chains_per_rank, (rank + 1) * chains_per_rank
@@ -30,6 +36,8 @@ def gather_summaries(local, world, group=None):
     likelihood).  Returns the [world*C, 2] tensor of all ranks, in global chain order."""
     if world == 1:
         return local
+    if local.is_cuda and _host_staged(group):
+        return gather_summaries(local.cpu(), world, group).to(local.device)
     if local.dim() == 3:  # [intervals, C, 2] from mcmcgpu_run_reported -> [intervals, world*C, 2]
         n, C, w = local.shape
         out = torch.empty((world, n, C, w), dtype=local.dtype, device=local.device)
@@ -52,8 +60,25 @@ def best_chain(all_summaries, chains_per_rank):
 def broadcast_from_owner(buf, owner, world, group=None):
     """Broadcast of the winner's packed state (relative poses + landmark estimates)."""
     if world > 1:
-        dist.broadcast(buf, src=owner, group=group)
+        if buf.is_cuda and _host_staged(group):
+            host = buf.cpu()
+            dist.broadcast(host, src=owner, group=group)
+            buf.copy_(host)
+        else:
+            dist.broadcast(buf, src=owner, group=group)
     return buf
+
+
+def all_reduce(t, op, world, group=None):
+    """In-place all-reduce of a tensor on any backend."""
+    if world > 1:
+        if t.is_cuda and _host_staged(group):
+            host = t.cpu()
+            dist.all_reduce(host, op=op, group=group)
+            t.copy_(host)
+        else:
+            dist.all_reduce(t, op=op, group=group)
+    return t
 
 
 def counts_of(all_summaries):
@@ -75,10 +100,8 @@ def average_over_ranks(g, chains_per_rank, rank, world, device, group=None):
     total = torch.zeros(n, dtype=torch.float64, device=device)
     if rank == 0:
         g.average_base(0, base.data_ptr())
-    if world > 1:
-        dist.broadcast(base, src=0, group=group)
+    broadcast_from_owner(base, 0, world, group)
     g.average_sum(base.data_ptr(), 0 if rank == 0 else -1, total.data_ptr())
-    if world > 1:
-        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+    all_reduce(total, dist.ReduceOp.SUM, world, group)
     g.average_finish(base.data_ptr(), total.data_ptr(), chains_per_rank * world)
     return base[:3 * T].view(T, 3), base[3 * T:].view(F, 2)
