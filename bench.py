@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Benchmark of the MCMC-SLAM proposal-evaluation path on MI355X.
 
-Metric (BASELINE.json): evaluated MCMC proposals*observations per second -- one
+Metric: evaluated MCMC proposals*observations per second -- one
 unit is one execution of the reference's inner loop body
 (src/slam/mcmc_slam.hpp:487-502), i.e. one range reading evaluated for one
 proposal of one chain -- summed over all chains of all GPUs of the node.
 
-Workload (BASELINE.json configs[2], per GPU): synthetic planar robot, 100k poses,
+Workload (per GPU): synthetic planar robot, 100k poses,
 1k landmarks, 1M range readings, 1024 independent chains.  A bench "step" is one
 launch of the on-device Metropolis-Hastings loop doing `--updates-per-step`
 updates (mcmc_slam::update) on every chain; the launch leaves one summary record
@@ -40,9 +40,9 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=["chains", "tempering", "range-bearing"], default="chains",
-                    help="chains: BASELINE.json configs[2] (the headline); tempering: configs[4], one ladder of "
+                    help="chains: the headline workload; tempering: one ladder of "
                          "tempered replicas per GPU on a 1M-pose trajectory with a replica exchange after every launch; "
-                         "range-bearing: configs[2] with the reference's other observation model (48 B per unit)")
+                         "range-bearing: the headline workload with the reference's other observation model (48 B per unit)")
     ap.add_argument("--bearing-stddev", type=float, default=0.05, help="range-bearing: sigma of the bearings, rad")
     ap.add_argument("--chains", type=int, default=None, help="chains per GPU (1024; tempering: 64)")
     ap.add_argument("--updates-per-step", type=int, default=None,
