@@ -504,3 +504,89 @@ def test_snapshot_is_the_state_at_its_place_in_the_stream():
     assert np.array_equal(a.log_likelihood(), b.log_likelihood())
     with pytest.raises(RuntimeError, match="no snapshot"):
         a.snapshot_wait(p["T"], p["F"])
+
+
+def _ragged_problem(seed, T=120, F=7):
+    """Hand-made awkward data: timesteps without readings, a landmark seen exactly once, readings at
+    timestep 0 and at the last timestep, ranges that shrink and grow (so re-parenting happens both ways)."""
+    rng = np.random.default_rng(seed)
+    base = small_problem(T=T, F=F, k=3, seed=seed)
+    keep = np.ones(base["N"], dtype=bool)
+    t = base["obs_t"]
+    keep &= ~((t % 7 == 3) | (t % 11 == 5))          # whole timesteps without any reading
+    keep &= rng.random(base["N"]) > 0.35             # ragged per-landmark lists
+    once = int(base["obs_f"][np.flatnonzero(keep)[-1]])
+    last_of_once = np.flatnonzero(keep & (base["obs_f"] == once))
+    keep[last_of_once[:-1]] = False                  # this landmark is seen exactly once, at the very end
+    idx = np.flatnonzero(keep)
+    obs_raw = base["obs_f"][idx]
+    _, first_pos = np.unique(obs_raw, return_index=True)  # renumber densely by first appearance
+    order = obs_raw[np.sort(first_pos)]
+    remap = np.full(base["F"], -1, dtype=np.int64)
+    remap[order] = np.arange(order.size)
+    p = dict(base)
+    p.update(obs_t=base["obs_t"][idx], obs_f=remap[obs_raw].astype(np.uint32), obs_mean=base["obs_mean"][idx],
+             obs_std=base["obs_std"][idx], N=int(idx.size), F=int(order.size))
+    return p
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_ragged_data_online_matches_oracle(seed):
+    p = _ragged_problem(seed)
+    assert p["obs_t"][0] == 0 and np.setdiff1d(np.arange(p["T"]), p["obs_t"]).size > 10
+    seeds = capi.seed_sequence(100 + seed, 3)
+    w = oracle_world(p, seeds, steps_per_timestep=4, end_steps=150)
+    w.replay(p["T"], finish=True)
+    g = gpu_handle(p, seeds, trace_capacity=2048)
+    g.advance(p["T"], steps_per_timestep=4, end_steps=150)
+    g.sync()
+    ll, full = g.log_likelihood(), g.full_log_likelihood()
+    for c in range(len(seeds)):
+        compare_traces(g.trace(c), w.trace(c), abs(w.log_likelihood(c)))
+        assert_close(ll[c], w.log_likelihood(c), REL, f"chain {c} final log likelihood")
+        assert_close(full[c], w.full_log_likelihood(c), REL, f"chain {c} full log likelihood")
+        assert np.array_equal(g.get_state(c)["feat_parent"], w.state(c)["feat_parent"])
+
+
+def test_no_readings_at_all_and_a_single_timestep():
+    """Only state edges (no landmark ever seen), and the smallest problem there is."""
+    p = small_problem(T=60, F=4, k=2, seed=9)
+    empty = np.zeros(0)
+    seeds = capi.seed_sequence(5, 2)
+    for T in (60, 1):
+        w = oracle_lib.World()
+        w.set_input(p["ctrl_mean"][:T], p["ctrl_std"][:T], empty.astype(np.uint32), empty.astype(np.uint32), empty, empty)
+        for s in seeds:
+            w.add_chain(int(s), steps_per_timestep=2, end_steps=50, trace=True)
+        w.replay(T, finish=True)
+        g = capi.McmcGpu(len(seeds), T, 1, 1, trace_capacity=512)
+        g.upload_problem(p["ctrl_mean"][:T], p["ctrl_std"][:T], empty, empty, empty, empty, 0)
+        g.init_chains(seeds)
+        g.advance(T, steps_per_timestep=2, end_steps=50)
+        g.sync()
+        for c in range(len(seeds)):
+            compare_traces(g.trace(c), w.trace(c), max(1.0, abs(w.log_likelihood(c))))
+            assert_close(g.log_likelihood()[c], w.log_likelihood(c), REL, "log likelihood")
+        assert g.dims()[1] == 0
+
+
+def test_capacity_and_argument_errors_are_reported():
+    p = small_problem(T=50, F=4, k=2, seed=2)
+    g = capi.McmcGpu(2, 40, 4, p["N"])  # too few timesteps
+    with pytest.raises(RuntimeError, match="capacities"):
+        g.upload_problem(p["ctrl_mean"], p["ctrl_std"], p["obs_t"], p["obs_f"], p["obs_mean"], p["obs_std"], p["F"])
+    g = capi.McmcGpu(2, p["T"], p["F"], p["N"])
+    with pytest.raises(RuntimeError, match="arrival order"):
+        g.upload_problem(p["ctrl_mean"], p["ctrl_std"], p["obs_t"][::-1].copy(), p["obs_f"], p["obs_mean"], p["obs_std"],
+                         p["F"])
+    with pytest.raises(RuntimeError, match="first appearance"):
+        g.upload_problem(p["ctrl_mean"], p["ctrl_std"], p["obs_t"], (p["F"] - 1 - p["obs_f"]).astype(np.uint32),
+                         p["obs_mean"], p["obs_std"], p["F"])
+    with pytest.raises(RuntimeError, match="timestep 0|upload a problem"):
+        g.init_chains(capi.seed_sequence(1, 2))
+        g.run(5)
+    g.upload_problem(p["ctrl_mean"], p["ctrl_std"], p["obs_t"], p["obs_f"], p["obs_mean"], p["obs_std"], p["F"])
+    with pytest.raises(RuntimeError, match="out of range"):
+        g.init_chains(capi.seed_sequence(1, 3))  # more chains than the handle was created for
+    with pytest.raises(RuntimeError, match="power of two"):
+        capi.McmcGpu(1, 10, 1, 1, threads_per_chain=96)
