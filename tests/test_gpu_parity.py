@@ -223,10 +223,11 @@ def test_other_workgroup_sizes(threads):
         compare_traces(g.trace(c), w.trace(c), abs(w.log_likelihood(c)))
 
 
-def test_plaza2_single_chain(plaza_dir):
-    """Plaza2, one chain on the GPU, --mcmc-slam --mcmc-steps 10 --mcmc-end-steps 1000 --sensor-range-stddev 1."""
+@pytest.mark.parametrize("name", ["Plaza2", "Plaza1"])
+def test_plaza_single_chain(plaza_dir, name):
+    """Plaza1 / Plaza2, one chain on the GPU, step for step: --mcmc-slam --mcmc-steps 10 --mcmc-end-steps 1000 --sensor-range-stddev 1."""
     w = oracle_lib.World()
-    w.load_plaza(plaza_dir, "Plaza2", 1.0)
+    w.load_plaza(plaza_dir, name, 1.0)
     inp = w.get_input()
     obs_f, order = oracle_lib.dense_features(inp["obs_id"])
     T, N = w.dims()
@@ -242,9 +243,9 @@ def test_plaza2_single_chain(plaza_dir):
     g.advance(T, steps_per_timestep=10, end_steps=1000)
     g.sync()
     compare_traces(g.trace(0), w.trace(0), abs(w.log_likelihood(0)))
-    assert_close(g.log_likelihood()[0], w.log_likelihood(0), REL, "Plaza2 final log likelihood")
-    assert_close(g.full_log_likelihood()[0], w.full_log_likelihood(0), REL, "Plaza2 full log likelihood")
-    assert_close(g.get_state(0)["cum"], w.state(0)["cum"], REL, "Plaza2 cumulative poses")
+    assert_close(g.log_likelihood()[0], w.log_likelihood(0), REL, f"{name} final log likelihood")
+    assert_close(g.full_log_likelihood()[0], w.full_log_likelihood(0), REL, f"{name} full log likelihood")
+    assert_close(g.get_state(0)["cum"], w.state(0)["cum"], REL, f"{name} cumulative poses")
 
 
 def test_load_state_then_run_matches_oracle():
