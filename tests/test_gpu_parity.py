@@ -591,3 +591,40 @@ def test_capacity_and_argument_errors_are_reported():
         g.init_chains(capi.seed_sequence(1, 3))  # more chains than the handle was created for
     with pytest.raises(RuntimeError, match="power of two"):
         capi.McmcGpu(1, 10, 1, 1, threads_per_chain=96)
+
+
+def test_full_size_problem_properties_and_oracle_spot_check():
+    """The benchmark's problem size (100 000 poses, 1 000 landmarks, 1 000 000 readings): two chains step
+    for step against the oracle, and on all chains the size-independent properties -- incremental equals
+    from-scratch log likelihood, a rebuild of the pose table changes nothing, counters add up."""
+    p = synthetic.make_problem(T=100_000, n_landmarks=1000, k_nearest=10, seed=12345)
+    C, steps = 32, 120
+    seeds = capi.seed_sequence(12347, C)
+    g = capi.McmcGpu(C, p["T"], p["F"], p["N"], trace_capacity=steps)
+    g.upload_problem(p["ctrl_mean"], p["ctrl_std"], p["obs_t"], p["obs_f"], p["obs_mean"], p["obs_std"], p["F"])
+    g.init_chains(seeds)
+    g.load_state(p["true_rel"], p["landmarks"])
+    g.sync()
+    ll0 = g.log_likelihood()
+    assert np.all(ll0 == ll0[0])  # every chain starts from the same state
+    g.run(steps)
+    g.sync()
+    ll, full = g.log_likelihood(), g.full_log_likelihood()
+    assert_close(ll, full, REL, "incremental vs from-scratch log likelihood, all chains")
+    upd, acc, units = g.counters()
+    assert np.all(upd == steps) and np.all(acc <= steps) and units.sum() > 1e8
+    cum_before = g.get_state(3)["cum"]
+    g.rebuild()
+    g.sync()
+    assert_close(g.get_state(3)["cum"], cum_before, REL, "pose table after a rebuild")
+    assert_close(g.full_log_likelihood(), full, REL, "log likelihood after a rebuild")
+    w = oracle_lib.World()
+    w.set_input(p["ctrl_mean"], p["ctrl_std"], p["obs_t"], p["obs_f"], p["obs_mean"], p["obs_std"])
+    w.replay(p["T"])
+    for c in (0, C - 1):
+        k = w.add_detached_chain(int(seeds[c]), trace=True)
+        w.load_state(k, p["true_rel"], np.arange(p["F"]), p["landmarks"])
+        assert_close(ll0[c], w.log_likelihood(k), REL, "log likelihood of the loaded state")
+        assert w.update(k, steps) >= 0
+        compare_traces(g.trace(c), w.trace(k), abs(w.log_likelihood(k)))
+        assert units[c] == w.units(k)
