@@ -59,6 +59,9 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-plaza", action="store_true")
+    ap.add_argument("--split-slices", type=int, default=0,
+                    help="run every update as a sequence of kernels with each proposal's reading stream cut into "
+                         "this many workgroups (mcmcgpu_run_split): for few, long chains")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="testing aid: all ranks share GPU 0 and exchange over gloo (RCCL refuses two ranks on one "
                          "device); exercises the N > 1 code path on a one-GPU box, its numbers mean nothing")
@@ -195,7 +198,8 @@ def main():
     stream = torch.cuda.Stream(dev)
     torch.cuda.set_stream(stream)
     g = capi.McmcGpu(C, T, F, N, device=local_rank,
-                     threads_per_chain=args.threads_per_chain, stream=stream.cuda_stream, range_bearing=bearing)
+                     threads_per_chain=args.threads_per_chain, stream=stream.cuda_stream, range_bearing=bearing,
+                     max_split_slices=args.split_slices)
     g.upload_problem(problem["ctrl_mean"], problem["ctrl_std"], problem["obs_t"], problem["obs_f"],
                      problem["obs_mean"], problem["obs_std"], F)
     if bearing:
@@ -214,7 +218,11 @@ def main():
     best = {"ll": float("-inf"), "chain": -1}
 
     def one_step(i):
-        g.run_reported(args.updates_per_step, args.report_every, summaries.data_ptr())
+        if args.split_slices:
+            g.run_split(args.updates_per_step, args.split_slices)
+            g.write_summaries(summaries[-1].data_ptr())  # one record per chain at the end of the step
+        else:
+            g.run_reported(args.updates_per_step, args.report_every, summaries.data_ptr())
         if args.rebuild_every and (i + 1) % args.rebuild_every == 0:
             g.rebuild()
         if tempering:
@@ -305,6 +313,7 @@ def main():
                 "chains_total": C * world,
                 "updates_per_step": args.updates_per_step,
                 "report_every": args.report_every,
+                "split_slices": args.split_slices,
                 "parallelism": "chains sharded %dx%d, per-interval summaries all-gathered every step" % (world, C),
                 "start_state": "generating trajectory and landmark positions (mcmcgpu_load_state)",
             },
@@ -315,7 +324,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "kernel": "advance_kernel",
+                "kernel": "split_* kernel sequence of one step" if args.split_slices else "advance_kernel",
                 "kernel_ms": kern_ms,
                 "launches": launches,
                 "algorithmic_bytes_per_launch": bytes_per_launch,

@@ -55,7 +55,10 @@ typedef struct mcmcgpu_config {
    * ships with; 1 = range_bearing_model (:21-117), every reading also carries a
    * bearing (mcmcgpu_set_bearings). */
   uint32_t range_bearing;
-  uint32_t reserved;          /* 0 */
+  /* Split mode (mcmcgpu_run_split): the most slices one proposal's reading
+   * stream may be cut into; 0 = no split mode, and no memory set aside for it
+   * (44 bytes per chain and landmark). */
+  uint32_t max_split_slices;
 } mcmcgpu_config;
 
 /* One Metropolis-Hastings step as recorded when trace_capacity > 0. */
@@ -170,6 +173,17 @@ int mcmcgpu_set_ladders(mcmcgpu_handle h, uint32_t replicas, const double* betas
 int mcmcgpu_exchange(mcmcgpu_handle h, uint32_t phase);
 int mcmcgpu_get_ladders(mcmcgpu_handle h, double* beta, uint32_t* slot_chain, double* reading_ll, uint64_t* attempts,
                         uint64_t* swaps);
+
+/* mcmcgpu_run with every update issued as a sequence of kernels, the reading
+ * stream of each proposal (the loop of mcmc_slam.hpp:476-505) cut into
+ * `slices` equal parts that run on different workgroups.  mcmcgpu_run gives a
+ * chain one workgroup, which is the right shape for hundreds of chains; a
+ * single mcmc_slam instance or a handful of tempered replicas on a long
+ * trajectory would leave most of the GPU idle.  Same proposals, same accept
+ * decisions, same random stream as mcmcgpu_run (the partial sums are added in
+ * slice order, so log ratios agree to rounding).  Range-only readings, after
+ * growth; slices <= max_split_slices of the config. */
+int mcmcgpu_run_split(mcmcgpu_handle h, uint32_t steps, uint32_t slices);
 
 /* edge_log_likelihood_ratio (mcmc_slam.hpp:432-474) for one given proposal on
  * one chain, without changing the chain.  For a state edge the value includes

@@ -26,7 +26,7 @@ class Config(ctypes.Structure):
         ("trace_capacity", ctypes.c_uint32),
         ("stream", ctypes.c_void_p),
         ("range_bearing", ctypes.c_uint32),
-        ("reserved", ctypes.c_uint32),
+        ("max_split_slices", ctypes.c_uint32),
     ]
 
 
@@ -59,6 +59,7 @@ EXPORTS = [
     "mcmcgpu_run",
     "mcmcgpu_run_reported",
     "mcmcgpu_get_reports",
+    "mcmcgpu_run_split",
     "mcmcgpu_set_ladders",
     "mcmcgpu_exchange",
     "mcmcgpu_get_ladders",
@@ -155,10 +156,11 @@ class McmcGpu:
     """One handle = C chains on one GPU."""
 
     def __init__(self, max_chains, max_timesteps, max_features, max_observations, device=0,
-                 threads_per_chain=0, feature_uniform_first=True, trace_capacity=0, stream=None, range_bearing=False):
+                 threads_per_chain=0, feature_uniform_first=True, trace_capacity=0, stream=None, range_bearing=False,
+                 max_split_slices=0):
         self.lib = load_library()
         cfg = Config(device, max_chains, max_timesteps, max_features, max_observations, threads_per_chain,
-                     1 if feature_uniform_first else 0, trace_capacity, stream, 1 if range_bearing else 0, 0)
+                     1 if feature_uniform_first else 0, trace_capacity, stream, 1 if range_bearing else 0, max_split_slices)
         self.h = ctypes.c_void_p()
         rc = self.lib.mcmcgpu_create(ctypes.byref(cfg), ctypes.byref(self.h))
         if rc != 0:
@@ -232,6 +234,10 @@ class McmcGpu:
         self._check(
             self.lib.mcmcgpu_run_reported(self.h, ctypes.c_uint32(steps), ctypes.c_uint32(report_every),
                                           ctypes.c_void_p(dev_ptr) if dev_ptr else None), "mcmcgpu_run_reported")
+
+    def run_split(self, steps, slices):
+        """`steps` updates per chain, each proposal's reading stream cut into `slices` workgroups."""
+        self._check(self.lib.mcmcgpu_run_split(self.h, ctypes.c_uint32(steps), ctypes.c_uint32(slices)), "mcmcgpu_run_split")
 
     def get_reports(self):
         """Records of the last run_reported(..., dev_ptr=None): structured array [intervals, C]."""

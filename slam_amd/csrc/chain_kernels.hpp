@@ -97,6 +97,20 @@ struct Dev {
   double* beta;          // [C]
   double* llc;           // [C] the control-model part of ll (tempering leaves it at full weight)
   uint32_t* slot_chain;  // [C]
+  // split mode: a chain's update as a sequence of kernels, its reading stream cut into slices
+  struct ChainCtl* ctl;  // [C] what the pieces of one update hand to each other
+  uint32_t* sp_seglo;    // [C][Fcap]   first record of landmark f's affected readings
+  uint32_t* sp_segpre;   // [C][Fcap+1] their count, then (after the scan) the prefix sums
+  double* sp_segw;       // [C][Fcap][4] old and moved landmark position
+  double* sp_partial;    // [C][max_slices]
+  uint32_t max_slices;
+};
+
+// The scalars an update's kernels hand on in split mode (in the persistent kernel they live in LDS).
+struct ChainCtl {
+  double Ws, Wf, new_pll, old_pll, q[3];
+  int32_t w_dirty, op, pending, use_weight;
+  uint32_t idx, total;
 };
 
 constexpr int kMaxSeg = 256;   // landmark segments evaluated per pass
@@ -1178,6 +1192,242 @@ __global__ void advance_kernel(Dev d, uint32_t first_tn, uint32_t Tcur0, uint32_
     for (int i = 0; i < 8; ++i) atomicAdd(&g_phase_cycles[i], (unsigned long long)S.phase[i]);
   }
 #endif
+  chain_state_store(d, c, S);
+}
+
+// ---------------------------------------------------------------------------
+// Split mode: ONE update of every chain as five kernels, so that a chain's reading stream can use
+// many workgroups.  One workgroup per chain cannot fill the GPU when there are few chains (a
+// single mcmc_slam instance, a ladder of tempered replicas on a long trajectory); here the stream
+// of one proposal is cut into `slices` equal parts.  Same arithmetic per reading as the persistent
+// kernel; the partial sums are added in slice order.  Range-only readings; updates after growth.
+
+MG_DEV void ctl_to_shared(const Dev& d, uint32_t c, Shared& S, uint32_t Tcur) {
+  const ChainCtl& k = d.ctl[c];
+  S.Tcur = Tcur;
+  S.Ws = k.Ws;
+  S.Wf = k.Wf;
+  S.w_dirty = k.w_dirty;
+  S.new_pll = k.new_pll;
+  S.old_pll = k.old_pll;
+  S.q[0] = k.q[0];
+  S.q[1] = k.q[1];
+  S.q[2] = k.q[2];
+  S.op = k.op;
+  S.idx = k.idx;
+  S.pending = k.pending;
+  S.use_weight = k.use_weight;
+}
+MG_DEV void shared_to_ctl(const Dev& d, uint32_t c, const Shared& S) {
+  ChainCtl& k = d.ctl[c];
+  k.Ws = S.Ws;
+  k.Wf = S.Wf;
+  k.w_dirty = S.w_dirty;
+  k.new_pll = S.new_pll;
+  k.old_pll = S.old_pll;
+  k.q[0] = S.q[0];
+  k.q[1] = S.q[1];
+  k.q[2] = S.q[2];
+  k.op = S.op;
+  k.idx = S.idx;
+  k.pending = S.pending;
+  k.use_weight = S.use_weight;
+}
+
+// 1: selection and proposal (mcmc_slam.hpp:339-382); grid = chains.  first = 1 on the first update
+// of a run: the weight totals are then computed afresh.
+__global__ void split_begin_kernel(Dev d_by_value, uint32_t Tcur, uint32_t first) {
+  MG_KERNEL_DEV(d);
+  __shared__ Shared S;
+  const uint32_t c = blockIdx.x;
+  chain_state_load(d, c, S);
+  if (threadIdx.x == 0) {
+    if (!first) ctl_to_shared(d, c, S, Tcur);
+    S.Tcur = Tcur;
+    S.op = OP_END;
+    if (d.errflag[c] || !driver_begin_update(d, c, S)) S.op = OP_END;
+    shared_to_ctl(d, c, S);
+  }
+  chain_state_store(d, c, S);
+}
+
+// 2: one lane per landmark: its affected readings and its old and moved position (phases A and B
+// of eval_state_edge, or the single segment of eval_feature_edge); grid = (ceil(nf / 256), chains).
+__global__ void split_setup_kernel(Dev d_by_value, uint32_t Tcur) {
+  MG_KERNEL_DEV(d);
+  const uint32_t c = blockIdx.y, f = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t nf = d.nf[c];
+  if (f >= nf) return;
+  const ChainCtl& k = d.ctl[c];
+  const size_t fi = size_t(c) * d.Fcap + f, si = size_t(c) * (d.Fcap + 1) + f;
+  uint32_t slo = d.foff[f], len = 0;
+  Vec2 w{0.0, 0.0}, wn{0.0, 0.0};
+  if (k.op == OP_EVAL_STATE) {
+    const uint32_t t = k.idx;
+    if (d.ffirst[f] <= t && t < d.flast[fi]) {
+      const Pose q{k.q[0], k.q[1], k.q[2]};
+      const Pose Pt = world_pose(d, c, t), Pt1 = world_pose(d, c, t + 1);
+      const uint32_t lo = d.foff[f], hi = lo + d.fcnt[fi], pt = d.fpt[fi];
+      const uint32_t a = split_readings(d, lo, hi, t);
+      w = act(world_pose(d, c, pt), Vec2{d.fex[fi], d.fey[fi]});
+      if (t < pt) {
+        wn = act(Pt, act(q, act_inverse(Pt1, w)));
+        slo = lo;
+        len = a - lo;
+      } else {
+        wn = act(Pt1, act(inverse(q), act_inverse(Pt, w)));
+        slo = a;
+        len = hi - a;
+      }
+    }
+  } else if (k.op == OP_EVAL_FEATURE && f == k.idx) {
+    const Pose Pp = world_pose(d, c, d.fpt[fi]);
+    w = act(Pp, Vec2{d.fex[fi], d.fey[fi]});
+    wn = act(Pp, Vec2{k.q[0], k.q[1]});
+    len = d.fcnt[fi];
+  }
+  d.sp_seglo[fi] = slo;
+  d.sp_segpre[si] = len;
+  double* o = d.sp_segw + 4 * fi;
+  o[0] = w.x;
+  o[1] = w.y;
+  o[2] = wn.x;
+  o[3] = wn.y;
+}
+
+// 3: counts -> exclusive prefix sums, in place; grid = chains.
+__global__ void split_scan_kernel(Dev d_by_value) {
+  MG_KERNEL_DEV(d);
+  __shared__ Shared S;
+  const uint32_t c = blockIdx.x, nf = d.nf[c];
+  uint32_t* pre = d.sp_segpre + size_t(c) * (d.Fcap + 1);
+  uint32_t carry = 0;
+  for (uint32_t f0 = 0; f0 < nf; f0 += blockDim.x) {
+    const uint32_t f = f0 + threadIdx.x;
+    const uint32_t v = f < nf ? pre[f] : 0;
+    uint32_t total;
+    const uint32_t incl = block_scan_u32(v, S, total);
+    if (f < nf) pre[f] = carry + incl - v;
+    carry += total;
+  }
+  if (threadIdx.x == 0) {
+    pre[nf] = carry;
+    d.ctl[c].total = carry;
+  }
+}
+
+// 4: the reading stream of one proposal, slice blockIdx.x of gridDim.x of chain blockIdx.y.
+__global__ void __launch_bounds__(256) split_eval_kernel(Dev d_by_value) {
+  MG_KERNEL_DEV(d);
+  __shared__ double red[4];
+  const uint32_t c = blockIdx.y, slices = gridDim.x, nf = d.nf[c];
+  const uint32_t* __restrict__ segpre = d.sp_segpre + size_t(c) * (d.Fcap + 1);
+  const uint32_t* __restrict__ seglo = d.sp_seglo + size_t(c) * d.Fcap;
+  const double* __restrict__ w4 = d.sp_segw + 4 * size_t(c) * d.Fcap;
+  const PoseXY* __restrict__ poses = d.pxy + size_t(c) * (d.Tcap + 1);
+  const uint32_t total = nf ? segpre[nf] : 0;
+  const uint32_t per = (total + slices - 1) / slices;
+  const uint32_t lo = min(total, blockIdx.x * per), hi = min(total, lo + per);
+  double acc = 0.0;
+  if (lo + threadIdx.x < hi) {
+    uint32_t cur;
+    {  // the segment that holds this lane's first reading: last f with segpre[f] <= i
+      uint32_t a = 0, b = nf;
+      const uint32_t i = lo + threadIdx.x;
+      while (a + 1 < b) {
+        const uint32_t m = (a + b) >> 1;
+        if (segpre[m] <= i)
+          a = m;
+        else
+          b = m;
+      }
+      cur = a;
+    }
+    uint32_t seg_end = segpre[cur + 1], seg_base = seglo[cur] - segpre[cur];
+    const bool usig = d.usig_inv > 0.0;
+    const double half_isd2 = 0.5 * d.usig_inv * d.usig_inv;
+    constexpr int U = 2;
+    constexpr uint32_t stride = 256;
+    for (uint32_t i0 = lo + threadIdx.x; i0 < hi; i0 += U * stride) {
+      uint32_t o[U], sg[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t i = i0 + u * stride;
+        if (i < hi) {
+          while (i >= seg_end) {
+            ++cur;
+            seg_end = segpre[cur + 1];
+            seg_base = seglo[cur] - segpre[cur];
+          }
+          o[u] = seg_base + i;
+        } else {
+          o[u] = seglo[0];
+        }
+        sg[u] = cur;
+      }
+      ObsRec rec[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) rec[u] = d.orec[o[u]];
+      PoseXY p[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) p[u] = poses[rec[u].t];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const double* w = w4 + 4 * size_t(sg[u]);
+        const double ro = range_of(w[0] - p[u].x, w[1] - p[u].y);
+        const double rn = range_of(w[2] - p[u].x, w[3] - p[u].y);
+        double k = half_isd2;
+        if (!usig) {
+          const double isd = d.oisd[o[u]];
+          k = 0.5 * isd * isd;
+        }
+        const double term = (ro - rn) * fma(-2.0, rec[u].mu, ro + rn) * k;
+        if (i0 + u * stride < hi) acc += term;
+      }
+    }
+  }
+#pragma unroll
+  for (int dd = 32; dd > 0; dd >>= 1) acc += __shfl_down(acc, dd);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) d.sp_partial[size_t(c) * d.max_slices + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// 5: the rest of the update (mcmc_slam.hpp:385-418) and, on an accepted state edge, the pose
+// table; grid = chains.
+__global__ void split_finish_kernel(Dev d_by_value, uint32_t Tcur, uint32_t slices) {
+  MG_KERNEL_DEV(d);
+  __shared__ Shared S;
+  const uint32_t c = blockIdx.x;
+  chain_state_load(d, c, S);
+  if (threadIdx.x == 0) {
+    ctl_to_shared(d, c, S, Tcur);
+    S.accept = 0;
+    S.n_upd = 1;
+    if (S.op != OP_END) {
+      double r = 0.0;
+      for (uint32_t k = 0; k < slices; ++k) r += d.sp_partial[size_t(c) * d.max_slices + k];
+      S.n_units = d.ctl[c].total;
+      if (S.op == OP_EVAL_STATE) S.n_state = 1;
+      const bool accept = driver_finish_update(d, c, S, r);
+      S.accept = accept ? 1 : 0;
+      if (accept) S.n_acc = 1;
+      S.pending = PEND_NONE;
+    }
+  }
+  __syncthreads();
+  if (S.op == OP_EVAL_STATE && S.accept) {
+    const Pose q{S.q[0], S.q[1], S.q[2]};
+    commit_state_edge(d, c, S.idx, q, Tcur);
+    if (threadIdx.x == 0) {
+      const size_t ri = size_t(c) * d.Tcap + S.idx;
+      d.relx[ri] = q.x;
+      d.rely[ri] = q.y;
+      d.relth[ri] = q.th;
+      S.n_moved = Tcur - S.idx;
+    }
+  }
+  if (threadIdx.x == 0) shared_to_ctl(d, c, S);
   chain_state_store(d, c, S);
 }
 

@@ -225,6 +225,14 @@ int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out) {
   ALLOC(h->scan_tot, C * d.NTcap);
   ALLOC(h->seed_stage, C);
   ALLOC(h->reports, size_t(kMaxOwnReports) * C);
+  d.max_slices = cfg->max_split_slices;
+  if (d.max_slices) {
+    ALLOC(d.ctl, C);
+    ALLOC(d.sp_seglo, C * d.Fcap);
+    ALLOC(d.sp_segpre, C * (size_t(d.Fcap) + 1));
+    ALLOC(d.sp_segw, 4 * C * d.Fcap);
+    ALLOC(d.sp_partial, C * d.max_slices);
+  }
   h->snap_doubles = 3 * size_t(d.Tcap) + 2 * size_t(d.Fcap) + 2;
   ALLOC(h->snap_dev, h->snap_doubles);
   if (!rc) {
@@ -535,6 +543,38 @@ int mcmcgpu_get_ladders(mcmcgpu_handle h, double* beta, uint32_t* slot_chain, do
   for (uint32_t c = 0; reading_ll && c < h->chains; ++c) reading_ll[c] = ll[c] - llc[c];
   if (attempts) *attempts = counts[0];
   if (swaps) *swaps = counts[1];
+  return 0;
+}
+
+int mcmcgpu_run_split(mcmcgpu_handle h, uint32_t steps, uint32_t slices) {
+  if (!h) return MCMCGPU_ERR_ARGUMENT;
+  if (!h->problem_loaded || h->chains == 0) return fail(h, MCMCGPU_ERR_STATE, "upload a problem and init chains first");
+  if (h->next_timestep == 0) return fail(h, MCMCGPU_ERR_STATE, "chains have not processed timestep 0 yet");
+  if (h->d.max_slices == 0) return fail(h, MCMCGPU_ERR_STATE, "the handle was created without split mode (max_split_slices)");
+  if (slices == 0 || slices > h->d.max_slices) return fail(h, MCMCGPU_ERR_ARGUMENT, "slices out of range");
+  if (h->cfg.range_bearing) return fail(h, MCMCGPU_ERR_STATE, "split mode evaluates range-only readings");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  const uint32_t T = edges_grown(h), C = h->chains;
+  const uint32_t fblocks = std::max<uint32_t>(1, (h->d.F + 255) / 256);
+  EventPair ev;  // the whole sequence counts as one timed launch (mcmcgpu_kernel_time)
+  if (!h->free_events.empty()) {
+    ev = h->free_events.back();
+    h->free_events.pop_back();
+  } else {
+    HIP_TRY(h, hipEventCreate(&ev.start));
+    HIP_TRY(h, hipEventCreate(&ev.stop));
+  }
+  HIP_TRY(h, hipEventRecord(ev.start, h->stream));
+  for (uint32_t i = 0; i < steps; ++i) {
+    hipLaunchKernelGGL(split_begin_kernel, dim3(C), dim3(256), 0, h->stream, h->d, T, i == 0 ? 1u : 0u);
+    hipLaunchKernelGGL(split_setup_kernel, dim3(fblocks, C), dim3(256), 0, h->stream, h->d, T);
+    hipLaunchKernelGGL(split_scan_kernel, dim3(C), dim3(256), 0, h->stream, h->d);
+    hipLaunchKernelGGL(split_eval_kernel, dim3(slices, C), dim3(256), 0, h->stream, h->d);
+    hipLaunchKernelGGL(split_finish_kernel, dim3(C), dim3(256), 0, h->stream, h->d, T, slices);
+    HIP_TRY(h, hipGetLastError());
+  }
+  HIP_TRY(h, hipEventRecord(ev.stop, h->stream));
+  h->timings.push_back(ev);
   return 0;
 }
 

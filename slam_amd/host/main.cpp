@@ -57,7 +57,8 @@ const char* const kFlags[] = {"dataset", "dataset-dir", "mcmc-slam", "mcmc-steps
                               "waypoint-file", "landmark-file", "dt", "sensor-skip", "sim-seed", "waypoint-repetitions",
                               "waypoint-proximity", "sensor-range-max", "sensor-range-min", "robot-speed",
                               "robot-max-steering", "robot-max-steering-rate", "controller-paramP",
-                              "controller-paramD", "controller-smoothing", "sensor-bearing-stddev"};
+                              "controller-paramD", "controller-smoothing", "sensor-bearing-stddev", "split-slices",
+                              "split-min-observations"};
 const char* const kSwitches[] = {"mcmc-slam", "multi-mcmc", "dump-loader", "help"};
 
 options parse(int argc, char** argv) {
@@ -179,6 +180,8 @@ int main(int argc, char** argv) try {
   cap.timesteps = std::uint32_t(std::size_t(dataset->current_timestep())) + 1;
   cap.observations = std::uint32_t(dataset->observations().size()) + 1;
   cap.features = 4096;
+  cap.split_slices = opt.uint("split-slices", cap.split_slices);
+  cap.split_min_observations = opt.uint("split-min-observations", cap.split_min_observations);
 
   std::shared_ptr<mcmc_slam_type> mcmc_slam;
   std::shared_ptr<mcmc_slam_type::updater> mcmc_slam_updater;

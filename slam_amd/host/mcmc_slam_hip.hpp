@@ -45,6 +45,10 @@ struct gpu_capacity {
   std::uint32_t timesteps = 1u << 20, features = 1u << 12, observations = 1u << 22;
   int device = 0;
   bool feature_uniform_first = true;  // draw order inside a landmark proposal, see mcmcgpu_config
+  // A single chain is one workgroup; on a large problem mcmc_slam::update spreads each proposal's
+  // reading stream over this many workgroups instead (mcmcgpu_run_split), once the data holds at
+  // least split_min_observations readings.  0 = never.
+  std::uint32_t split_slices = 64, split_min_observations = 200000;
 };
 
 namespace detail {
@@ -130,6 +134,16 @@ class mcmc_slam : public slam_result_of<ControlModel, ObservationModel> {
   std::vector<double> init_rel, init_feat;  // what the initialiser says about new edges
   std::size_t next_timestep = 0;
   std::uint64_t accepts_seen = 0;
+  std::uint32_t split_slices = 0, split_min_observations = 0;
+
+  // `count` updates, queued: one persistent launch, or kernel sequences with sliced reading streams
+  void run_updates(unsigned int count) {
+    const bool split = split_slices && !decltype(problem)::bearing && problem.N() >= split_min_observations;
+    if (split)
+      detail::check(h, mcmcgpu_run_split(h, count, split_slices), "mcmcgpu_run_split");
+    else
+      detail::check(h, mcmcgpu_run(h, count), "mcmcgpu_run");
+  }
 
   // host mirrors for the slam_result read interface, rebuilt on demand
   mutable trajectory_type trajectory_mirror;
@@ -148,6 +162,9 @@ class mcmc_slam : public slam_result_of<ControlModel, ObservationModel> {
     cfg.max_observations = cap.observations;
     cfg.feature_uniform_first = cap.feature_uniform_first ? 1 : 0;
     cfg.range_bearing = decltype(problem)::bearing ? 1 : 0;
+    cfg.max_split_slices = decltype(problem)::bearing ? 0 : cap.split_slices;
+    split_slices = cfg.max_split_slices;
+    split_min_observations = cap.split_min_observations;
     if (mcmcgpu_create(&cfg, &h) != 0) throw std::runtime_error(std::string("mcmcgpu_create: ") + mcmcgpu_last_error(nullptr));
     const std::uint32_t s = seed;
     detail::check(h, mcmcgpu_init_chains(h, 1, &s, nullptr, 0), "mcmcgpu_init_chains");
@@ -170,7 +187,7 @@ class mcmc_slam : public slam_result_of<ControlModel, ObservationModel> {
   // `count` steps in one launch; returns how many were accepted.
   unsigned int update(unsigned int count) {
     if (next_timestep == 0 || count == 0) return 0;
-    detail::check(h, mcmcgpu_run(h, count), "mcmcgpu_run");
+    run_updates(count);
     std::uint64_t acc = 0;
     detail::check(h, mcmcgpu_get_counters(h, nullptr, &acc, nullptr), "mcmcgpu_get_counters");
     detail::check(h, mcmcgpu_sync(h), "mcmcgpu_sync");
@@ -261,7 +278,7 @@ class mcmc_slam : public slam_result_of<ControlModel, ObservationModel> {
   // updates queued without waiting for them (update(count) waits, to report the accept count)
   void update_async(unsigned int count) {
     if (next_timestep == 0 || count == 0) return;
-    detail::check(h, mcmcgpu_run(h, count), "mcmcgpu_run");
+    run_updates(count);
     invalidate();
   }
 

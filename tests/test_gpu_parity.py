@@ -628,3 +628,36 @@ def test_full_size_problem_properties_and_oracle_spot_check():
         assert w.update(k, steps) >= 0
         compare_traces(g.trace(c), w.trace(k), abs(w.log_likelihood(k)))
         assert units[c] == w.units(k)
+
+
+@pytest.mark.parametrize("slices,uniform_sigma", [(1, True), (3, True), (8, False)])
+def test_split_mode_matches_oracle(slices, uniform_sigma):
+    """mcmcgpu_run_split: every update as a sequence of kernels with the reading stream cut into slices --
+    the same steps as the oracle (and so as the one-workgroup-per-chain kernel)."""
+    p = small_problem(T=600, F=20, k=5, seed=23)
+    if not uniform_sigma:
+        p = dict(p)
+        p["obs_std"] = p["obs_std"] * (1.0 + 0.3 * np.sin(np.arange(p["N"])))
+    seeds = capi.seed_sequence(808, 3)
+    steps = 400
+    w = oracle_world(p, seeds)
+    w.replay(p["T"])
+    g = gpu_handle(p, seeds, trace_capacity=4096, max_split_slices=8)
+    g.grow(p["T"])
+    g.run_split(150, slices)
+    g.run(100)                      # the two ways of running mix freely
+    g.run_split(steps - 250, slices)
+    g.sync()
+    ll, full = g.log_likelihood(), g.full_log_likelihood()
+    upd, acc, units = g.counters()
+    for c in range(len(seeds)):
+        assert w.update(c, steps) >= 0
+        compare_traces(g.trace(c), w.trace(c), abs(w.log_likelihood(c)))
+        assert_close(ll[c], w.log_likelihood(c), REL, f"chain {c} final log likelihood")
+        assert_close(ll[c], full[c], 1e-8, f"chain {c} incremental vs full")
+        assert_close(g.get_state(c)["cum"], w.state(c)["cum"], REL, "cumulative poses")
+        assert units[c] == w.units(c) and upd[c] == steps
+    plain = gpu_handle(p, seeds, trace_capacity=0)
+    with pytest.raises(RuntimeError, match="without split mode"):
+        plain.grow(p["T"])
+        plain.run_split(5, 2)

@@ -224,3 +224,16 @@ def test_range_bearing_run_through_the_drop_in_classes():
     w.replay(w.dims()[0], finish=True)
     ref = w.log_likelihood(c)
     assert abs(ll - ref) <= 1e-9 * abs(ref), (ll, ref)
+
+
+@pytest.mark.gpu
+def test_single_chain_split_mode_gives_the_same_run():
+    """--mcmc-slam through the drop-in class with the reading stream of every proposal spread over several
+    workgroups (forced on for this small data set): same final log likelihood as the one-workgroup run."""
+    args = ["--dataset", "Plaza2", "--dataset-dir", PLAZA, "--mcmc-slam", "--mcmc-steps", "3", "--mcmc-end-steps", "400",
+            "--sensor-range-stddev", "1", "--seed", "42"]
+    lls = []
+    for extra in (["--split-slices", "0"], ["--split-slices", "4", "--split-min-observations", "1"]):
+        out = run(*args, *extra)
+        lls.append(float([ln for ln in out.splitlines() if ln.startswith("MCMC-SLAM log likelihood")][0].split()[-1]))
+    assert abs(lls[0] - lls[1]) <= 1e-9 * abs(lls[0]), lls
