@@ -1196,7 +1196,7 @@ __global__ void advance_kernel(Dev d, uint32_t first_tn, uint32_t Tcur0, uint32_
 }
 
 // ---------------------------------------------------------------------------
-// Split mode: ONE update of every chain as five kernels, so that a chain's reading stream can use
+// Split mode: ONE update of every chain as four kernels, so that a chain's reading stream can use
 // many workgroups.  One workgroup per chain cannot fill the GPU when there are few chains (a
 // single mcmc_slam instance, a ladder of tempered replicas on a long trajectory); here the stream
 // of one proposal is cut into `slices` equal parts.  Same arithmetic per reading as the persistent
@@ -1234,24 +1234,57 @@ MG_DEV void shared_to_ctl(const Dev& d, uint32_t c, const Shared& S) {
   k.use_weight = S.use_weight;
 }
 
-// 1: selection and proposal (mcmc_slam.hpp:339-382); grid = chains.  first = 1 on the first update
-// of a run: the weight totals are then computed afresh.
-__global__ void split_begin_kernel(Dev d_by_value, uint32_t Tcur, uint32_t first) {
+// The serial ends of an update, one workgroup per chain: the END of update k -- sum of the slices,
+// accept test (mcmc_slam.hpp:385-418), pose table of an accepted state edge -- and the BEGINNING of
+// update k + 1 -- selection and proposal (:339-382) -- in one kernel, so that the chain's generator
+// and scalars are fetched once for both.  finish = 0 on the first call of a run (nothing to end;
+// the weight totals are computed afresh), begin = 0 on the last.
+__global__ void split_ends_kernel(Dev d_by_value, uint32_t Tcur, uint32_t slices, uint32_t finish, uint32_t begin) {
   MG_KERNEL_DEV(d);
   __shared__ Shared S;
   const uint32_t c = blockIdx.x;
   chain_state_load(d, c, S);
   if (threadIdx.x == 0) {
-    if (!first) ctl_to_shared(d, c, S, Tcur);
     S.Tcur = Tcur;
+    S.accept = 0;
     S.op = OP_END;
-    if (d.errflag[c] || !driver_begin_update(d, c, S)) S.op = OP_END;
+    if (finish) {
+      ctl_to_shared(d, c, S, Tcur);
+      S.n_upd = 1;
+      if (S.op != OP_END) {
+        double r = 0.0;
+        for (uint32_t k = 0; k < slices; ++k) r += d.sp_partial[size_t(c) * d.max_slices + k];
+        S.n_units = d.ctl[c].total;
+        if (S.op == OP_EVAL_STATE) S.n_state = 1;
+        const bool accept = driver_finish_update(d, c, S, r);
+        S.accept = accept ? 1 : 0;
+        if (accept) S.n_acc = 1;
+        S.pending = PEND_NONE;
+      }
+    }
+  }
+  __syncthreads();
+  if (S.op == OP_EVAL_STATE && S.accept) {
+    const Pose q{S.q[0], S.q[1], S.q[2]};
+    commit_state_edge(d, c, S.idx, q, Tcur);
+    if (threadIdx.x == 0) {
+      const size_t ri = size_t(c) * d.Tcap + S.idx;
+      d.relx[ri] = q.x;
+      d.rely[ri] = q.y;
+      d.relth[ri] = q.th;
+      S.n_moved = Tcur - S.idx;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    S.op = OP_END;
+    if (begin && !S.failed && !d.errflag[c] && !driver_begin_update(d, c, S)) S.op = OP_END;
     shared_to_ctl(d, c, S);
   }
   chain_state_store(d, c, S);
 }
 
-// 2: one lane per landmark: its affected readings and its old and moved position (phases A and B
+// One lane per landmark: its affected readings and its old and moved position (phases A and B
 // of eval_state_edge, or the single segment of eval_feature_edge); grid = (ceil(nf / 256), chains).
 __global__ void split_setup_kernel(Dev d_by_value, uint32_t Tcur) {
   MG_KERNEL_DEV(d);
@@ -1295,7 +1328,7 @@ __global__ void split_setup_kernel(Dev d_by_value, uint32_t Tcur) {
   o[3] = wn.y;
 }
 
-// 3: counts -> exclusive prefix sums, in place; grid = chains.
+// Counts -> exclusive prefix sums, in place; grid = chains.
 __global__ void split_scan_kernel(Dev d_by_value) {
   MG_KERNEL_DEV(d);
   __shared__ Shared S;
@@ -1316,7 +1349,7 @@ __global__ void split_scan_kernel(Dev d_by_value) {
   }
 }
 
-// 4: the reading stream of one proposal, slice blockIdx.x of gridDim.x of chain blockIdx.y.
+// The reading stream of one proposal, slice blockIdx.x of gridDim.x of chain blockIdx.y.
 __global__ void __launch_bounds__(256) split_eval_kernel(Dev d_by_value) {
   MG_KERNEL_DEV(d);
   __shared__ double red[4];
@@ -1391,44 +1424,6 @@ __global__ void __launch_bounds__(256) split_eval_kernel(Dev d_by_value) {
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) d.sp_partial[size_t(c) * d.max_slices + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-}
-
-// 5: the rest of the update (mcmc_slam.hpp:385-418) and, on an accepted state edge, the pose
-// table; grid = chains.
-__global__ void split_finish_kernel(Dev d_by_value, uint32_t Tcur, uint32_t slices) {
-  MG_KERNEL_DEV(d);
-  __shared__ Shared S;
-  const uint32_t c = blockIdx.x;
-  chain_state_load(d, c, S);
-  if (threadIdx.x == 0) {
-    ctl_to_shared(d, c, S, Tcur);
-    S.accept = 0;
-    S.n_upd = 1;
-    if (S.op != OP_END) {
-      double r = 0.0;
-      for (uint32_t k = 0; k < slices; ++k) r += d.sp_partial[size_t(c) * d.max_slices + k];
-      S.n_units = d.ctl[c].total;
-      if (S.op == OP_EVAL_STATE) S.n_state = 1;
-      const bool accept = driver_finish_update(d, c, S, r);
-      S.accept = accept ? 1 : 0;
-      if (accept) S.n_acc = 1;
-      S.pending = PEND_NONE;
-    }
-  }
-  __syncthreads();
-  if (S.op == OP_EVAL_STATE && S.accept) {
-    const Pose q{S.q[0], S.q[1], S.q[2]};
-    commit_state_edge(d, c, S.idx, q, Tcur);
-    if (threadIdx.x == 0) {
-      const size_t ri = size_t(c) * d.Tcap + S.idx;
-      d.relx[ri] = q.x;
-      d.rely[ri] = q.y;
-      d.relth[ri] = q.th;
-      S.n_moved = Tcur - S.idx;
-    }
-  }
-  if (threadIdx.x == 0) shared_to_ctl(d, c, S);
-  chain_state_store(d, c, S);
 }
 
 // edge_log_likelihood_ratio for a caller-supplied proposal; grid = 1.

@@ -565,12 +565,13 @@ int mcmcgpu_run_split(mcmcgpu_handle h, uint32_t steps, uint32_t slices) {
     HIP_TRY(h, hipEventCreate(&ev.stop));
   }
   HIP_TRY(h, hipEventRecord(ev.start, h->stream));
+  // ends(begin 1) | setup, scan, eval, ends(finish k, begin k+1) | ... : 1 + 4 * steps launches
+  if (steps) hipLaunchKernelGGL(split_ends_kernel, dim3(C), dim3(256), 0, h->stream, h->d, T, slices, 0u, 1u);
   for (uint32_t i = 0; i < steps; ++i) {
-    hipLaunchKernelGGL(split_begin_kernel, dim3(C), dim3(256), 0, h->stream, h->d, T, i == 0 ? 1u : 0u);
     hipLaunchKernelGGL(split_setup_kernel, dim3(fblocks, C), dim3(256), 0, h->stream, h->d, T);
     hipLaunchKernelGGL(split_scan_kernel, dim3(C), dim3(256), 0, h->stream, h->d);
     hipLaunchKernelGGL(split_eval_kernel, dim3(slices, C), dim3(256), 0, h->stream, h->d);
-    hipLaunchKernelGGL(split_finish_kernel, dim3(C), dim3(256), 0, h->stream, h->d, T, slices);
+    hipLaunchKernelGGL(split_ends_kernel, dim3(C), dim3(256), 0, h->stream, h->d, T, slices, 1u, i + 1 < steps ? 1u : 0u);
     HIP_TRY(h, hipGetLastError());
   }
   HIP_TRY(h, hipEventRecord(ev.stop, h->stream));
