@@ -132,23 +132,29 @@ def cpu_baseline(problem, seed, target_seconds, all_seeds=None):
 
 def plaza1_wall(device, with_cpu):
     """Plaza1 --mcmc-slam --mcmc-steps 10 --mcmc-end-steps 1000 --sensor-range-stddev 1: wall time of the
-    whole online replay, one chain on the GPU (and the CPU oracle beside it)."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib
-    from slam_amd import capi
+    whole online replay, one chain on the GPU (and the CPU oracle beside it).  The GPU leg reads the logs
+    with the shipped loader (the host program leaves a binary cache behind) and never touches the oracle."""
+    import subprocess
+    import tempfile
+
+    from slam_amd import capi, dataset_cache, synthetic
 
     plaza = os.path.join(ROOT, "tests", "golden", "plaza")
-    w = oracle_lib.World()  # used here as the data loader and, optionally, the CPU timing
-    w.load_plaza(plaza, "Plaza1", 1.0)
-    inp = w.get_input()
-    obs_f, order = oracle_lib.dense_features(inp["obs_id"])
-    T, N = w.dims()
+    exe = os.path.join(ROOT, "slam_amd", "host", "slam_hip")
+    with tempfile.TemporaryDirectory() as tmp:
+        cache = os.path.join(tmp, "plaza1.slamro")
+        subprocess.check_call([exe, "--dataset", "Plaza1", "--dataset-dir", plaza, "--dataset-cache", cache,
+                               "--dump-loader"], stdout=subprocess.DEVNULL)
+        data = dataset_cache.read(cache)
+    T, N = data["T"], data["N"]
+    ctrl_mean, ctrl_std = synthetic.control_models(data["controls"], data["dt"])
+    obs_f, order = dataset_cache.dense_landmarks(data["obs_id"])
+    obs_std = np.full(N, 1.0)
     seeds = capi.seed_sequence(42, 6)
     out = {}
     g = capi.McmcGpu(1, T, len(order), N, device=device)
     t0 = time.perf_counter()
-    g.upload_problem(inp["ctrl_mean"], inp["ctrl_std"], inp["obs_t"], obs_f, inp["obs_mean"], inp["obs_std"],
-                     len(order))
+    g.upload_problem(ctrl_mean, ctrl_std, data["obs_t"], obs_f, data["obs_range"], obs_std, len(order))
     g.init_chains(np.array([seeds[2]], dtype=np.uint32), capi.uniform_sequence(int(seeds[1]), len(order)))
     g.advance(T, steps_per_timestep=10, end_steps=1000)
     g.sync()
@@ -156,6 +162,11 @@ def plaza1_wall(device, with_cpu):
     out["gpu_log_likelihood"] = float(g.log_likelihood()[0])
     g.close()
     if with_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib
+
+        w = oracle_lib.World()
+        w.load_plaza(plaza, "Plaza1", 1.0)
         w.set_initialiser(int(seeds[1]))
         w.add_chain(int(seeds[2]), steps_per_timestep=10, end_steps=1000, use_initialiser=True)
         t0 = time.perf_counter()

@@ -64,3 +64,14 @@ def read(path):
         obs_id = take("<u4", Np)[:N].copy()
         obs_range = take("<f8", N)
     return {"T": T, "N": N, "dt": dt, "controls": controls, "obs_t": obs_t, "obs_id": obs_id, "obs_range": obs_range}
+
+
+def dense_landmarks(obs_id):
+    """Landmark ids -> (dense indices numbered by first appearance, the ids in that order): the numbering
+    the C ABI takes (the index into the reference's feature_estimates vector)."""
+    obs_id = np.asarray(obs_id)
+    _, first = np.unique(obs_id, return_index=True)
+    order = obs_id[np.sort(first)]
+    remap = np.full(int(obs_id.max()) + 1 if obs_id.size else 1, -1, dtype=np.int64)
+    remap[order] = np.arange(order.size)
+    return remap[obs_id].astype(np.uint32), order

@@ -65,6 +65,14 @@ def test_dataset_cache_round_trip(name, tmp_path):
     assert np.array_equal(d["obs_t"], inp["obs_t"]) and np.array_equal(d["obs_id"], inp["obs_id"])
     assert np.array_equal(d["obs_range"], inp["obs_mean"])
     assert np.array_equal(d["dt"][:, None] * d["controls"], inp["ctrl_mean"])
+    # the Python control-model builder and landmark numbering (what bench.py feeds the GPU) equal the oracle's
+    from slam_amd import synthetic
+
+    cm, cs = synthetic.control_models(d["controls"], d["dt"])
+    assert np.array_equal(cm, inp["ctrl_mean"]) and np.array_equal(cs, inp["ctrl_std"])
+    dense, order = dataset_cache.dense_landmarks(d["obs_id"])
+    dense_o, order_o = oracle_lib.dense_features(inp["obs_id"])
+    assert np.array_equal(dense, dense_o) and np.array_equal(order, order_o)
     # and a cache written from Python reads back identically in C++
     again = str(tmp_path / "again.slamro")
     dataset_cache.write(again, d["dt"], d["controls"], d["obs_t"], d["obs_id"], d["obs_range"])
