@@ -65,8 +65,8 @@ def main():
                   f"coalesced stream, so reads are in [{fv * 1024:.4g}, {2 * fv * 1024:.4g}] B")
             print(f"WRITE_SIZE {wv * 1024:.4g} B")
             if bench:
-                # what bench.py quotes as roofline.traffic for the same workload: reads doubled (the upper
-                # end of the bracket; the gathered 16-byte pose reads are not a calibrated pattern) + writes
+                # what bench.py quotes as roofline.traffic for the same workload: reads doubled (calibrated on
+                # this gather pattern with tools/stream_probe: FETCH_SIZE tallies it at about half) + writes
                 rec = {"workload": bench["config"]["workload"], "updates_per_step": bench["config"]["updates_per_step"],
                        "fetch_size_reported_bytes": fv * 1024, "write_size_bytes": wv * 1024,
                        "traffic_bytes_per_launch": 2 * fv * 1024 + wv * 1024, "launches_averaged": n}
