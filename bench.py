@@ -130,8 +130,8 @@ def cpu_baseline(problem, seed, target_seconds, all_seeds=None):
     return out
 
 
-def plaza1_wall(device, with_cpu):
-    """Plaza1 --mcmc-slam --mcmc-steps 10 --mcmc-end-steps 1000 --sensor-range-stddev 1: wall time of the
+def plaza_wall(name, device, with_cpu):
+    """Plaza1 / Plaza2 --mcmc-slam --mcmc-steps 10 --mcmc-end-steps 1000 --sensor-range-stddev 1: wall time of the
     whole online replay, one chain on the GPU (and the CPU oracle beside it).  The GPU leg reads the logs
     with the shipped loader (the host program leaves a binary cache behind) and never touches the oracle."""
     import subprocess
@@ -142,8 +142,8 @@ def plaza1_wall(device, with_cpu):
     plaza = os.path.join(ROOT, "tests", "golden", "plaza")
     exe = os.path.join(ROOT, "slam_amd", "host", "slam_hip")
     with tempfile.TemporaryDirectory() as tmp:
-        cache = os.path.join(tmp, "plaza1.slamro")
-        subprocess.check_call([exe, "--dataset", "Plaza1", "--dataset-dir", plaza, "--dataset-cache", cache,
+        cache = os.path.join(tmp, name + ".slamro")
+        subprocess.check_call([exe, "--dataset", name, "--dataset-dir", plaza, "--dataset-cache", cache,
                                "--dump-loader"], stdout=subprocess.DEVNULL)
         data = dataset_cache.read(cache)
     T, N = data["T"], data["N"]
@@ -166,7 +166,7 @@ def plaza1_wall(device, with_cpu):
         import oracle_lib
 
         w = oracle_lib.World()
-        w.load_plaza(plaza, "Plaza1", 1.0)
+        w.load_plaza(plaza, name, 1.0)
         w.set_initialiser(int(seeds[1]))
         w.add_chain(int(seeds[2]), steps_per_timestep=10, end_steps=1000, use_initialiser=True)
         t0 = time.perf_counter()
@@ -355,7 +355,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(problem, all_seeds[0], args.cpu_seconds, all_seeds)
         if world == 1 and not args.no_plaza:
             g.close()
-            out["plaza1"] = plaza1_wall(local_rank, with_cpu=not args.no_cpu_baseline)
+            out["plaza1"] = plaza_wall("Plaza1", local_rank, with_cpu=not args.no_cpu_baseline)
+            out["plaza2"] = plaza_wall("Plaza2", local_rank, with_cpu=not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -44,8 +44,12 @@ def main():
         if "cpu_baseline" in bench:
             c = bench["cpu_baseline"]
             print(f"cpu_baseline: {c['value']:.4g} {c['unit']} on {c['cores']} core ({c['sample']})")
-        if "plaza1" in bench:
-            print("plaza1:", bench["plaza1"])
+        for name in ("plaza1", "plaza2"):
+            if name in bench:
+                print(name + ":", bench[name])
+        if "cpu_baseline" in bench and "all_cores" in bench["cpu_baseline"]:
+            a = bench["cpu_baseline"]["all_cores"]
+            print(f"cpu, one chain per thread: {a['value']:.4g} on {a['cores']} threads ({a['sample']})")
     stats = first(os.path.join(out, "stats", "**", "*kernel_stats.csv"))
     if stats:
         print("== rocprofv3 --kernel-trace --stats (same bench command, 2 warm-up + 6 timed launches) ==")
