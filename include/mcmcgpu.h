@@ -181,8 +181,8 @@ int mcmcgpu_get_ladders(mcmcgpu_handle h, double* beta, uint32_t* slot_chain, do
  * single mcmc_slam instance or a handful of tempered replicas on a long
  * trajectory would leave most of the GPU idle.  Same proposals, same accept
  * decisions, same random stream as mcmcgpu_run (the partial sums are added in
- * slice order, so log ratios agree to rounding).  Range-only readings, after
- * growth; slices <= max_split_slices of the config. */
+ * slice order, so log ratios agree to rounding).  For updates after growth;
+ * slices <= max_split_slices of the config. */
 int mcmcgpu_run_split(mcmcgpu_handle h, uint32_t steps, uint32_t slices);
 
 /* edge_log_likelihood_ratio (mcmc_slam.hpp:432-474) for one given proposal on

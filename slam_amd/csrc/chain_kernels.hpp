@@ -1200,7 +1200,7 @@ __global__ void advance_kernel(Dev d, uint32_t first_tn, uint32_t Tcur0, uint32_
 // many workgroups.  One workgroup per chain cannot fill the GPU when there are few chains (a
 // single mcmc_slam instance, a ladder of tempered replicas on a long trajectory); here the stream
 // of one proposal is cut into `slices` equal parts.  Same arithmetic per reading as the persistent
-// kernel; the partial sums are added in slice order.  Range-only readings; updates after growth.
+// kernel; the partial sums are added in slice order.  Updates after growth.
 
 MG_DEV void ctl_to_shared(const Dev& d, uint32_t c, Shared& S, uint32_t Tcur) {
   const ChainCtl& k = d.ctl[c];
@@ -1232,6 +1232,61 @@ MG_DEV void shared_to_ctl(const Dev& d, uint32_t c, const Shared& S) {
   k.idx = S.idx;
   k.pending = S.pending;
   k.use_weight = S.use_weight;
+}
+
+// The reading stream of one proposal for range-and-bearing readings (the arithmetic of
+// eval_segments_rb<false>), slice blockIdx.x of gridDim.x of chain blockIdx.y.
+__global__ void __launch_bounds__(256) split_eval_rb_kernel(Dev d_by_value) {
+  MG_KERNEL_DEV(d);
+  __shared__ double red[4];
+  const uint32_t c = blockIdx.y, slices = gridDim.x, nf = d.nf[c];
+  const uint32_t* __restrict__ segpre = d.sp_segpre + size_t(c) * (d.Fcap + 1);
+  const uint32_t* __restrict__ seglo = d.sp_seglo + size_t(c) * d.Fcap;
+  const double* __restrict__ w4 = d.sp_segw + 4 * size_t(c) * d.Fcap;
+  const PoseXY* __restrict__ poses = d.pxy + size_t(c) * (d.Tcap + 1);
+  const double* __restrict__ pth = d.pth + size_t(c) * (d.Tcap + 1);
+  const uint32_t total = nf ? segpre[nf] : 0;
+  const uint32_t per = (total + slices - 1) / slices;
+  const uint32_t lo = min(total, blockIdx.x * per), hi = min(total, lo + per);
+  double acc = 0.0;
+  if (lo + threadIdx.x < hi) {
+    uint32_t cur;
+    {
+      uint32_t a = 0, b = nf;
+      const uint32_t i = lo + threadIdx.x;
+      while (a + 1 < b) {
+        const uint32_t m = (a + b) >> 1;
+        if (segpre[m] <= i)
+          a = m;
+        else
+          b = m;
+      }
+      cur = a;
+    }
+    uint32_t seg_end = segpre[cur + 1], seg_base = seglo[cur] - segpre[cur];
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
+      while (i >= seg_end) {
+        ++cur;
+        seg_end = segpre[cur + 1];
+        seg_base = seglo[cur] - segpre[cur];
+      }
+      const uint32_t o = seg_base + i;
+      const ObsRec rec = d.orec[o];
+      const double bm = d.obear[o], isd = d.oisd[o], ibsd = d.obisd[o];
+      const PoseXY p = poses[rec.t];
+      const double th = pth[rec.t];
+      const double* w = w4 + 4 * size_t(cur);
+      const double ox = w[0] - p.x, oy = w[1] - p.y, nx = w[2] - p.x, ny = w[3] - p.y;
+      const double ro = range_of(ox, oy), rn = range_of(nx, ny);
+      const double eo = wrap_residual(atan2(oy, ox) - th - bm), en = wrap_residual(atan2(ny, nx) - th - bm);
+      acc += (ro - rn) * fma(-2.0, rec.mu, ro + rn) * (0.5 * isd * isd) + (eo - en) * (eo + en) * (0.5 * ibsd * ibsd);
+    }
+  }
+#pragma unroll
+  for (int dd = 32; dd > 0; dd >>= 1) acc += __shfl_down(acc, dd);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) d.sp_partial[size_t(c) * d.max_slices + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // The serial ends of an update, one workgroup per chain: the END of update k -- sum of the slices,

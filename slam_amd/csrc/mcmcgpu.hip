@@ -552,7 +552,8 @@ int mcmcgpu_run_split(mcmcgpu_handle h, uint32_t steps, uint32_t slices) {
   if (h->next_timestep == 0) return fail(h, MCMCGPU_ERR_STATE, "chains have not processed timestep 0 yet");
   if (h->d.max_slices == 0) return fail(h, MCMCGPU_ERR_STATE, "the handle was created without split mode (max_split_slices)");
   if (slices == 0 || slices > h->d.max_slices) return fail(h, MCMCGPU_ERR_ARGUMENT, "slices out of range");
-  if (h->cfg.range_bearing) return fail(h, MCMCGPU_ERR_STATE, "split mode evaluates range-only readings");
+  if (h->cfg.range_bearing && !h->bearings_loaded)
+    return fail(h, MCMCGPU_ERR_STATE, "mcmcgpu_set_bearings must follow mcmcgpu_upload_problem on a range-and-bearing handle");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   const uint32_t T = edges_grown(h), C = h->chains;
   const uint32_t fblocks = std::max<uint32_t>(1, (h->d.F + 255) / 256);
@@ -570,7 +571,10 @@ int mcmcgpu_run_split(mcmcgpu_handle h, uint32_t steps, uint32_t slices) {
   for (uint32_t i = 0; i < steps; ++i) {
     hipLaunchKernelGGL(split_setup_kernel, dim3(fblocks, C), dim3(256), 0, h->stream, h->d, T);
     hipLaunchKernelGGL(split_scan_kernel, dim3(C), dim3(256), 0, h->stream, h->d);
-    hipLaunchKernelGGL(split_eval_kernel, dim3(slices, C), dim3(256), 0, h->stream, h->d);
+    if (h->cfg.range_bearing)
+      hipLaunchKernelGGL(split_eval_rb_kernel, dim3(slices, C), dim3(256), 0, h->stream, h->d);
+    else
+      hipLaunchKernelGGL(split_eval_kernel, dim3(slices, C), dim3(256), 0, h->stream, h->d);
     hipLaunchKernelGGL(split_ends_kernel, dim3(C), dim3(256), 0, h->stream, h->d, T, slices, 1u, i + 1 < steps ? 1u : 0u);
     HIP_TRY(h, hipGetLastError());
   }

@@ -138,7 +138,7 @@ class mcmc_slam : public slam_result_of<ControlModel, ObservationModel> {
 
   // `count` updates, queued: one persistent launch, or kernel sequences with sliced reading streams
   void run_updates(unsigned int count) {
-    const bool split = split_slices && !decltype(problem)::bearing && problem.N() >= split_min_observations;
+    const bool split = split_slices && problem.N() >= split_min_observations;
     if (split)
       detail::check(h, mcmcgpu_run_split(h, count, split_slices), "mcmcgpu_run_split");
     else
@@ -162,7 +162,7 @@ class mcmc_slam : public slam_result_of<ControlModel, ObservationModel> {
     cfg.max_observations = cap.observations;
     cfg.feature_uniform_first = cap.feature_uniform_first ? 1 : 0;
     cfg.range_bearing = decltype(problem)::bearing ? 1 : 0;
-    cfg.max_split_slices = decltype(problem)::bearing ? 0 : cap.split_slices;
+    cfg.max_split_slices = cap.split_slices;
     split_slices = cfg.max_split_slices;
     split_min_observations = cap.split_min_observations;
     if (mcmcgpu_create(&cfg, &h) != 0) throw std::runtime_error(std::string("mcmcgpu_create: ") + mcmcgpu_last_error(nullptr));

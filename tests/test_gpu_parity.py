@@ -661,3 +661,27 @@ def test_split_mode_matches_oracle(slices, uniform_sigma):
     with pytest.raises(RuntimeError, match="without split mode"):
         plain.grow(p["T"])
         plain.run_split(5, 2)
+
+
+def test_split_mode_with_range_bearing_readings():
+    p = _rb_problem(T=300, F=12, k=4, seed=13)
+    seeds = capi.seed_sequence(333, 2)
+    steps = 300
+    w = oracle_lib.World()
+    w.set_input(p["ctrl_mean"], p["ctrl_std"], p["obs_t"], p["obs_f"], p["obs_mean"], p["obs_std"])
+    w.set_bearings(p["obs_bearing"], p["obs_bearing_std"])
+    for s in seeds:
+        w.add_chain(int(s), trace=True)
+    w.replay(p["T"])
+    g = capi.McmcGpu(len(seeds), p["T"], p["F"], p["N"], trace_capacity=4096, range_bearing=True, max_split_slices=4)
+    g.upload_problem(p["ctrl_mean"], p["ctrl_std"], p["obs_t"], p["obs_f"], p["obs_mean"], p["obs_std"], p["F"])
+    g.set_bearings(p["obs_bearing"], p["obs_bearing_std"])
+    g.init_chains(seeds)
+    g.grow(p["T"])
+    g.run_split(steps, 4)
+    g.sync()
+    ll = g.log_likelihood()
+    for c in range(len(seeds)):
+        assert w.update(c, steps) >= 0
+        compare_traces(g.trace(c), w.trace(c), abs(w.log_likelihood(c)))
+        assert_close(ll[c], w.log_likelihood(c), REL, f"chain {c} final log likelihood")
