@@ -66,6 +66,7 @@ struct Dev {
   const double* obear;        // [Ncap] measured bearing
   const double* obsd;         // [Ncap] its std deviation
   const double* obisd;        // [Ncap] 1 / that
+  double ubsig_inv;           // 1/sigma of the bearings when they all have the same sigma, else 0
   // ---- chains --------------------------------------------------------------
   uint32_t C, NTcap;
   double *relx, *rely, *relth;  // [C][Tcap]   relative pose of state edge t
@@ -259,6 +260,16 @@ __global__ void range_selftest_kernel(uint32_t n, const double* dx, const double
   if (i < n) out[i] = range_of(dx[i], dy[i]);
 }
 
+// a - 2 pi rint(a / 2 pi): the angle brought into [-pi, pi] (2 pi in two parts, so the reduction
+// of an angle of hundreds of radians keeps its last bits).  The reference's wrap_angle
+// (src/utility/geometry.hpp:8-16) maps to [-pi, pi); the two differ only at +-pi itself, and the
+// residual is squared.
+MG_DEV double wrap_residual(double a) {
+  constexpr double kTwoPiHi = 6.283185307179586232, kTwoPiLo = 2.4492935982947064e-16;
+  const double k = rint(a * (1.0 / kTwoPiHi));
+  return fma(-k, kTwoPiLo, fma(-k, kTwoPiHi, a));
+}
+
 // ---------------------------------------------------------------------------
 // The hot loop: sum over the prepared segments of
 //   ll(|w_new - t_s|) - ll(|w_old - t_s|)                      (mcmc_slam.hpp:487-502)
@@ -274,27 +285,35 @@ __global__ void range_selftest_kernel(uint32_t n, const double* dx, const double
 // The two buffer parities are written out as two half-steps so every buffer
 // is a fixed set of registers.  The segment cursor lives in registers; LDS is
 // read again only when a lane crosses into another segment.
-template <bool USIG>
+//
+// BEAR: range-and-bearing readings (see eval_segments_rb for the arithmetic) -- a record brings its
+// measured bearing along, a pose its angle; USIG then means that the ranges AND the bearings each
+// have one sigma for all readings.
+template <bool USIG, bool BEAR = false, int U_ = 4>
 struct RatioStream {
-  static constexpr int U = 4;  // readings per lane per group
+  static constexpr int U = U_;  // readings per lane per group
   struct Recs {
     uint32_t t[U], sg[U], o[U];
     double mu[U];
+    double bm[BEAR ? U : 1];
   };
   struct Poses {
     PoseXY p[U];
+    double th[BEAR ? U : 1];
   };
   const Dev& d;
   const Shared& S;
   const PoseXY* __restrict__ pxy;
+  const double* __restrict__ pth;
   const uint32_t total, stride;
-  const double half_isd2;
+  const double half_isd2, half_ibsd2;
   uint32_t cur = 0, seg_end, seg_base;
   double acc = 0.0;
 
   MG_DEV RatioStream(const Dev& d_, uint32_t c, const Shared& S_, uint32_t nseg)
-      : d(d_), S(S_), pxy(d_.pxy + size_t(c) * (d_.Tcap + 1)), total(S_.segpre[nseg]), stride(blockDim.x),
-        half_isd2(0.5 * d_.usig_inv * d_.usig_inv), seg_end(S_.segpre[1]), seg_base(S_.seglo[0]) {}
+      : d(d_), S(S_), pxy(d_.pxy + size_t(c) * (d_.Tcap + 1)), pth(d_.pth + size_t(c) * (d_.Tcap + 1)),
+        total(S_.segpre[nseg]), stride(blockDim.x), half_isd2(0.5 * d_.usig_inv * d_.usig_inv),
+        half_ibsd2(0.5 * d_.ubsig_inv * d_.ubsig_inv), seg_end(S_.segpre[1]), seg_base(S_.seglo[0]) {}
 
   MG_DEV void request_records(uint32_t i0, Recs& r) {
     if (i0 >= total) return;
@@ -320,25 +339,37 @@ struct RatioStream {
       const ObsRec rec = d.orec[r.o[u]];
       r.t[u] = rec.t;
       r.mu[u] = rec.mu;
+      if (BEAR) r.bm[u] = d.obear[r.o[u]];
     }
   }
   MG_DEV void request_poses(uint32_t i0, const Recs& r, Poses& p) {
     if (i0 >= total) return;
 #pragma unroll
-    for (int u = 0; u < U; ++u) p.p[u] = pxy[r.t[u]];
+    for (int u = 0; u < U; ++u) {
+      p.p[u] = pxy[r.t[u]];
+      if (BEAR) p.th[u] = pth[r.t[u]];
+    }
   }
   MG_DEV void step(uint32_t i0, Recs& r_this, const Recs& r_next, const Poses& p_this, Poses& p_next) {
     const uint32_t group = U * stride;
-    double mu[U], k[U];
+    double mu[U], k[U], bm[BEAR ? U : 1], kb[BEAR ? U : 1];
     uint32_t sg[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       mu[u] = r_this.mu[u];
       sg[u] = r_this.sg[u];
       k[u] = half_isd2;
+      if (BEAR) {
+        bm[u] = r_this.bm[u];
+        kb[u] = half_ibsd2;
+      }
       if (!USIG) {
         const double isd = d.oisd[r_this.o[u]];
         k[u] = 0.5 * isd * isd;
+        if (BEAR) {
+          const double ibsd = d.obisd[r_this.o[u]];
+          kb[u] = 0.5 * ibsd * ibsd;
+        }
       }
     }
     request_poses(i0 + group, r_next, p_next);
@@ -346,9 +377,16 @@ struct RatioStream {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const double* w = S.segw[sg[u]];
-      const double ro = range_of(w[0] - p_this.p[u].x, w[1] - p_this.p[u].y);
-      const double rn = range_of(w[2] - p_this.p[u].x, w[3] - p_this.p[u].y);
-      const double term = (ro - rn) * fma(-2.0, mu[u], ro + rn) * k[u];
+      const double ox = w[0] - p_this.p[u].x, oy = w[1] - p_this.p[u].y;
+      const double nx = w[2] - p_this.p[u].x, ny = w[3] - p_this.p[u].y;
+      const double ro = range_of(ox, oy);
+      const double rn = range_of(nx, ny);
+      double term = (ro - rn) * fma(-2.0, mu[u], ro + rn) * k[u];
+      if (BEAR) {
+        const double eo = wrap_residual(atan2(oy, ox) - p_this.th[u] - bm[u]);
+        const double en = wrap_residual(atan2(ny, nx) - p_this.th[u] - bm[u]);
+        term += (eo - en) * (eo + en) * kb[u];
+      }
       if (i0 + u * stride < total) acc += term;
     }
   }
@@ -448,16 +486,6 @@ MG_DEV double eval_segments(const Dev& d, uint32_t c, const Shared& S, uint32_t 
   return acc;
 }
 
-// a - 2 pi rint(a / 2 pi): the angle brought into [-pi, pi] (2 pi in two parts, so the reduction
-// of an angle of hundreds of radians keeps its last bits).  The reference's wrap_angle
-// (src/utility/geometry.hpp:8-16) maps to [-pi, pi); the two differ only at +-pi itself, and the
-// residual is squared.
-MG_DEV double wrap_residual(double a) {
-  constexpr double kTwoPiHi = 6.283185307179586232, kTwoPiLo = 2.4492935982947064e-16;
-  const double k = rint(a * (1.0 / kTwoPiHi));
-  return fma(-k, kTwoPiLo, fma(-k, kTwoPiHi, a));
-}
-
 // The same loops for range-AND-bearing readings (range_bearing_model,
 // src/planar_robot/range_bearing_model.hpp:21-117).  Seen from pose s the landmark is at
 // R(-th_s) (w - t_s): its range is |w - t_s| and its bearing atan2(w - t_s) - th_s, so a reading
@@ -531,7 +559,15 @@ MG_DEV double eval_segments_rb(const Dev& d, uint32_t c, const Shared& S, uint32
 }
 
 MG_PIECE double piece_ratio_rb(DevArgs dp, SharedLds sp, uint32_t c, uint32_t nseg) {
-  return eval_segments_rb<false>(*(const Dev*)dp, c, *(const Shared*)sp, nseg);
+  const Dev& d = *(const Dev*)dp;
+  const Shared& S = *(const Shared*)sp;
+  // one sigma for all ranges and one for all bearings (what the reference's model holds,
+  // range_bearing_model.hpp:21-117) -> no per-reading loads of them
+  // Two readings per lane per group: the two atan2 of a reading make this stream VALU-heavy (about
+  // 200 fp64 instructions per reading), so deeper groups buy nothing (one per lane: -4 %) and four
+  // per lane spill (-50 %).
+  if (d.usig_inv > 0.0 && d.ubsig_inv > 0.0) return RatioStream<true, true, 2>(d, c, S, nseg).run();
+  return RatioStream<false, true, 2>(d, c, S, nseg).run();
 }
 
 // Landmark edge (mcmc_slam.hpp:468-474): every reading of landmark f seen so
@@ -1248,6 +1284,8 @@ __global__ void __launch_bounds__(256) split_eval_rb_kernel(Dev d_by_value) {
   const uint32_t total = nf ? segpre[nf] : 0;
   const uint32_t per = (total + slices - 1) / slices;
   const uint32_t lo = min(total, blockIdx.x * per), hi = min(total, lo + per);
+  const bool usig = d.usig_inv > 0.0 && d.ubsig_inv > 0.0;
+  const double half_isd2 = 0.5 * d.usig_inv * d.usig_inv, half_ibsd2 = 0.5 * d.ubsig_inv * d.ubsig_inv;
   double acc = 0.0;
   if (lo + threadIdx.x < hi) {
     uint32_t cur;
@@ -1272,14 +1310,20 @@ __global__ void __launch_bounds__(256) split_eval_rb_kernel(Dev d_by_value) {
       }
       const uint32_t o = seg_base + i;
       const ObsRec rec = d.orec[o];
-      const double bm = d.obear[o], isd = d.oisd[o], ibsd = d.obisd[o];
+      const double bm = d.obear[o];
+      double kr = half_isd2, kb = half_ibsd2;
+      if (!usig) {
+        const double isd = d.oisd[o], ibsd = d.obisd[o];
+        kr = 0.5 * isd * isd;
+        kb = 0.5 * ibsd * ibsd;
+      }
       const PoseXY p = poses[rec.t];
       const double th = pth[rec.t];
       const double* w = w4 + 4 * size_t(cur);
       const double ox = w[0] - p.x, oy = w[1] - p.y, nx = w[2] - p.x, ny = w[3] - p.y;
       const double ro = range_of(ox, oy), rn = range_of(nx, ny);
       const double eo = wrap_residual(atan2(oy, ox) - th - bm), en = wrap_residual(atan2(ny, nx) - th - bm);
-      acc += (ro - rn) * fma(-2.0, rec.mu, ro + rn) * (0.5 * isd * isd) + (eo - en) * (eo + en) * (0.5 * ibsd * ibsd);
+      acc += (ro - rn) * fma(-2.0, rec.mu, ro + rn) * kr + (eo - en) * (eo + en) * kb;
     }
   }
 #pragma unroll

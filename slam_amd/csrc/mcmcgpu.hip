@@ -348,6 +348,7 @@ int mcmcgpu_upload_problem(mcmcgpu_handle h, uint32_t T, const double* ctrl_mean
   d.usig_inv = uniform_sigma ? 1.0 / obs_stddev[0] : 0.0;
   h->h_tobs = tobs;
   h->bearings_loaded = false;
+  d.ubsig_inv = 0.0;
   h->h_foff = foff;
   h->h_ot = ot;
   h->h_omu = omu;
@@ -362,8 +363,10 @@ int mcmcgpu_set_bearings(mcmcgpu_handle h, uint32_t N, const double* bearing_mea
     return fail(h, MCMCGPU_ERR_ARGUMENT, "one bearing per reading of the uploaded problem is required");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   std::vector<double> mu(N), sd(N), isd(N);
+  bool uniform_sigma = N > 0;
   for (uint32_t i = 0; i < N; ++i) {
     if (!(bearing_stddev[i] > 0)) return fail(h, MCMCGPU_ERR_ARGUMENT, "non-positive bearing stddev");
+    uniform_sigma = uniform_sigma && bearing_stddev[i] == bearing_stddev[0];
     const uint32_t pos = h->h_tobs[i];
     mu[pos] = bearing_mean[i];
     sd[pos] = bearing_stddev[i];
@@ -376,6 +379,7 @@ int mcmcgpu_set_bearings(mcmcgpu_handle h, uint32_t N, const double* bearing_mea
     HIP_TRY(h, hipMemcpyAsync(const_cast<double*>(h->d.obisd), isd.data(), bytes, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
   }
+  h->d.ubsig_inv = uniform_sigma ? 1.0 / bearing_stddev[0] : 0.0;
   h->bearings_loaded = true;
   return 0;
 }

@@ -685,3 +685,38 @@ def test_split_mode_with_range_bearing_readings():
         assert w.update(c, steps) >= 0
         compare_traces(g.trace(c), w.trace(c), abs(w.log_likelihood(c)))
         assert_close(ll[c], w.log_likelihood(c), REL, f"chain {c} final log likelihood")
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_range_bearing_with_a_sigma_per_reading(split):
+    """Readings whose range and bearing deviations differ from one to the next: the stream then loads
+    both per reading instead of holding one pair in registers."""
+    p = _rb_problem(T=300, F=12, k=4, seed=13)
+    rng = np.random.default_rng(5)
+    p["obs_std"] = p["obs_std"] * rng.uniform(1.0, 1.6, size=p["N"])
+    p["obs_bearing_std"] = p["obs_bearing_std"] * rng.uniform(1.0, 1.6, size=p["N"])
+    seeds = capi.seed_sequence(808, 2)
+    steps = 300
+    w = oracle_lib.World()
+    w.set_input(p["ctrl_mean"], p["ctrl_std"], p["obs_t"], p["obs_f"], p["obs_mean"], p["obs_std"])
+    w.set_bearings(p["obs_bearing"], p["obs_bearing_std"])
+    for s in seeds:
+        w.add_chain(int(s), trace=True)
+    w.replay(p["T"])
+    g = capi.McmcGpu(len(seeds), p["T"], p["F"], p["N"], trace_capacity=4096, range_bearing=True,
+                     max_split_slices=4 if split else 0)
+    g.upload_problem(p["ctrl_mean"], p["ctrl_std"], p["obs_t"], p["obs_f"], p["obs_mean"], p["obs_std"], p["F"])
+    g.set_bearings(p["obs_bearing"], p["obs_bearing_std"])
+    g.init_chains(seeds)
+    g.grow(p["T"])
+    if split:
+        g.run_split(steps, 4)
+    else:
+        g.run(steps)
+    g.sync()
+    ll, full = g.log_likelihood(), g.full_log_likelihood()
+    for c in range(len(seeds)):
+        assert w.update(c, steps) >= 0
+        compare_traces(g.trace(c), w.trace(c), abs(w.log_likelihood(c)))
+        assert_close(ll[c], w.log_likelihood(c), REL, f"chain {c} final log likelihood")
+        assert_close(full[c], w.full_log_likelihood(c), REL, f"chain {c} full log likelihood")
