@@ -285,21 +285,115 @@ MG_DEV double wrap_residual(double a) {
 // The two buffer parities are written out as two half-steps so every buffer
 // is a fixed set of registers.  The segment cursor lives in registers; LDS is
 // read again only when a lane crosses into another segment.
-//
-// BEAR: range-and-bearing readings (see eval_segments_rb for the arithmetic) -- a record brings its
-// measured bearing along, a pose its angle; USIG then means that the ranges AND the bearings each
-// have one sigma for all readings.
-template <bool USIG, bool BEAR = false, int U_ = 4>
+template <bool USIG>
 struct RatioStream {
-  static constexpr int U = U_;  // readings per lane per group
+  static constexpr int U = 4;  // readings per lane per group
   struct Recs {
     uint32_t t[U], sg[U], o[U];
     double mu[U];
-    double bm[BEAR ? U : 1];
   };
   struct Poses {
     PoseXY p[U];
-    double th[BEAR ? U : 1];
+  };
+  const Dev& d;
+  const Shared& S;
+  const PoseXY* __restrict__ pxy;
+  const uint32_t total, stride;
+  const double half_isd2;
+  uint32_t cur = 0, seg_end, seg_base;
+  double acc = 0.0;
+
+  MG_DEV RatioStream(const Dev& d_, uint32_t c, const Shared& S_, uint32_t nseg)
+      : d(d_), S(S_), pxy(d_.pxy + size_t(c) * (d_.Tcap + 1)), total(S_.segpre[nseg]), stride(blockDim.x),
+        half_isd2(0.5 * d_.usig_inv * d_.usig_inv), seg_end(S_.segpre[1]), seg_base(S_.seglo[0]) {}
+
+  MG_DEV void request_records(uint32_t i0, Recs& r) {
+    if (i0 >= total) return;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t i = i0 + u * stride;
+      if (i < total) {
+        if (i >= seg_end) {
+          do {
+            ++cur;
+            seg_end = S.segpre[cur + 1];
+          } while (i >= seg_end);
+          seg_base = S.seglo[cur] - S.segpre[cur];
+        }
+        r.o[u] = seg_base + i;
+      } else {
+        r.o[u] = S.seglo[0];
+      }
+      r.sg[u] = cur;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const ObsRec rec = d.orec[r.o[u]];
+      r.t[u] = rec.t;
+      r.mu[u] = rec.mu;
+    }
+  }
+  MG_DEV void request_poses(uint32_t i0, const Recs& r, Poses& p) {
+    if (i0 >= total) return;
+#pragma unroll
+    for (int u = 0; u < U; ++u) p.p[u] = pxy[r.t[u]];
+  }
+  MG_DEV void step(uint32_t i0, Recs& r_this, const Recs& r_next, const Poses& p_this, Poses& p_next) {
+    const uint32_t group = U * stride;
+    double mu[U], k[U];
+    uint32_t sg[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      mu[u] = r_this.mu[u];
+      sg[u] = r_this.sg[u];
+      k[u] = half_isd2;
+      if (!USIG) {
+        const double isd = d.oisd[r_this.o[u]];
+        k[u] = 0.5 * isd * isd;
+      }
+    }
+    request_poses(i0 + group, r_next, p_next);
+    request_records(i0 + 2 * group, r_this);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const double* w = S.segw[sg[u]];
+      const double ro = range_of(w[0] - p_this.p[u].x, w[1] - p_this.p[u].y);
+      const double rn = range_of(w[2] - p_this.p[u].x, w[3] - p_this.p[u].y);
+      const double term = (ro - rn) * fma(-2.0, mu[u], ro + rn) * k[u];
+      if (i0 + u * stride < total) acc += term;
+    }
+  }
+  MG_DEV double run() {
+    const uint32_t group = U * stride;
+    Recs r0, r1;
+    Poses p0, p1;
+    const uint32_t first = threadIdx.x;
+    request_records(first, r0);
+    request_records(first + group, r1);
+    request_poses(first, r0, p0);
+    for (uint32_t i0 = first; i0 < total; i0 += 2 * group) {
+      step(i0, r0, r1, p0, p1);
+      if (i0 + group < total) step(i0 + group, r1, r0, p1, p0);
+    }
+    return acc;
+  }
+};
+
+// The same pipeline for range-AND-bearing readings (arithmetic: see eval_segments_rb): a record
+// brings its measured bearing along, a pose its angle.  USIG here means that the ranges and the
+// bearings each have one sigma for all readings.  A struct of its own, so that the range-only
+// stream's code does not change with it (sharing one template cost the range-only stream 5 %).
+template <bool USIG>
+struct BearingStream {
+  static constexpr int U = 2;  // readings per lane per group (one: -4 %; four spill: -50 %)
+  struct Recs {
+    uint32_t t[U], sg[U], o[U];
+    double mu[U];
+    double bm[U];
+  };
+  struct Poses {
+    PoseXY p[U];
+    double th[U];
   };
   const Dev& d;
   const Shared& S;
@@ -310,7 +404,7 @@ struct RatioStream {
   uint32_t cur = 0, seg_end, seg_base;
   double acc = 0.0;
 
-  MG_DEV RatioStream(const Dev& d_, uint32_t c, const Shared& S_, uint32_t nseg)
+  MG_DEV BearingStream(const Dev& d_, uint32_t c, const Shared& S_, uint32_t nseg)
       : d(d_), S(S_), pxy(d_.pxy + size_t(c) * (d_.Tcap + 1)), pth(d_.pth + size_t(c) * (d_.Tcap + 1)),
         total(S_.segpre[nseg]), stride(blockDim.x), half_isd2(0.5 * d_.usig_inv * d_.usig_inv),
         half_ibsd2(0.5 * d_.ubsig_inv * d_.ubsig_inv), seg_end(S_.segpre[1]), seg_base(S_.seglo[0]) {}
@@ -339,7 +433,7 @@ struct RatioStream {
       const ObsRec rec = d.orec[r.o[u]];
       r.t[u] = rec.t;
       r.mu[u] = rec.mu;
-      if (BEAR) r.bm[u] = d.obear[r.o[u]];
+      r.bm[u] = d.obear[r.o[u]];
     }
   }
   MG_DEV void request_poses(uint32_t i0, const Recs& r, Poses& p) {
@@ -347,29 +441,24 @@ struct RatioStream {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       p.p[u] = pxy[r.t[u]];
-      if (BEAR) p.th[u] = pth[r.t[u]];
+      p.th[u] = pth[r.t[u]];
     }
   }
   MG_DEV void step(uint32_t i0, Recs& r_this, const Recs& r_next, const Poses& p_this, Poses& p_next) {
     const uint32_t group = U * stride;
-    double mu[U], k[U], bm[BEAR ? U : 1], kb[BEAR ? U : 1];
+    double mu[U], k[U], bm[U], kb[U];
     uint32_t sg[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       mu[u] = r_this.mu[u];
       sg[u] = r_this.sg[u];
+      bm[u] = r_this.bm[u];
       k[u] = half_isd2;
-      if (BEAR) {
-        bm[u] = r_this.bm[u];
-        kb[u] = half_ibsd2;
-      }
+      kb[u] = half_ibsd2;
       if (!USIG) {
-        const double isd = d.oisd[r_this.o[u]];
+        const double isd = d.oisd[r_this.o[u]], ibsd = d.obisd[r_this.o[u]];
         k[u] = 0.5 * isd * isd;
-        if (BEAR) {
-          const double ibsd = d.obisd[r_this.o[u]];
-          kb[u] = 0.5 * ibsd * ibsd;
-        }
+        kb[u] = 0.5 * ibsd * ibsd;
       }
     }
     request_poses(i0 + group, r_next, p_next);
@@ -381,12 +470,9 @@ struct RatioStream {
       const double nx = w[2] - p_this.p[u].x, ny = w[3] - p_this.p[u].y;
       const double ro = range_of(ox, oy);
       const double rn = range_of(nx, ny);
-      double term = (ro - rn) * fma(-2.0, mu[u], ro + rn) * k[u];
-      if (BEAR) {
-        const double eo = wrap_residual(atan2(oy, ox) - p_this.th[u] - bm[u]);
-        const double en = wrap_residual(atan2(ny, nx) - p_this.th[u] - bm[u]);
-        term += (eo - en) * (eo + en) * kb[u];
-      }
+      const double eo = wrap_residual(atan2(oy, ox) - p_this.th[u] - bm[u]);
+      const double en = wrap_residual(atan2(ny, nx) - p_this.th[u] - bm[u]);
+      const double term = (ro - rn) * fma(-2.0, mu[u], ro + rn) * k[u] + (eo - en) * (eo + en) * kb[u];
       if (i0 + u * stride < total) acc += term;
     }
   }
@@ -406,13 +492,25 @@ struct RatioStream {
   }
 };
 
-// range-and-bearing readings: a piece of its own, so that its registers are not the range-only
-// stream's problem
-MG_PIECE double piece_ratio_rb(DevArgs dp, SharedLds sp, uint32_t c, uint32_t nseg);
+// The stream of one pass.  RB (range-and-bearing readings) is a compile-time choice made where the
+// kernel calls its evaluation piece: each model's evaluation is then a piece with registers of its
+// own.  (As a run-time branch to a bearing piece from inside the range-only evaluation it cost the
+// range-only stream 5 %: live values of the caller saved around a call it never makes.)
+// The bearing stream is once more a piece inside its evaluation piece: inlined there, next to the
+// landmark set-up, it spills (1.0e11 instead of 1.2e11 units/s).
+MG_PIECE double piece_bearing_stream(DevArgs dp, SharedLds sp, uint32_t c, uint32_t nseg) {
+  const Dev& d = *(const Dev*)dp;
+  const Shared& S = *(const Shared*)sp;
+  // one sigma for all ranges and one for all bearings (what the reference's model holds,
+  // range_bearing_model.hpp:21-117) -> no per-reading loads of them
+  if (d.usig_inv > 0.0 && d.ubsig_inv > 0.0) return BearingStream<true>(d, c, S, nseg).run();
+  return BearingStream<false>(d, c, S, nseg).run();
+}
 
+template <bool RB>
 MG_DEV double eval_ratio(const Dev& d, uint32_t c, const Shared& S, uint32_t nseg) {
   // `d` is the argument block itself here (see MG_KERNEL_DEV), S the chain's LDS block
-  if (d.obear) return piece_ratio_rb((DevArgs)&d, (SharedLds)&S, c, nseg);
+  if (RB) return piece_bearing_stream((DevArgs)&d, (SharedLds)&S, c, nseg);
   // every reading has the same sigma (what the reference's builder produces) -> no per-reading load of it
   if (d.usig_inv > 0.0) return RatioStream<true>(d, c, S, nseg).run();
   return RatioStream<false>(d, c, S, nseg).run();
@@ -558,20 +656,9 @@ MG_DEV double eval_segments_rb(const Dev& d, uint32_t c, const Shared& S, uint32
   return acc;
 }
 
-MG_PIECE double piece_ratio_rb(DevArgs dp, SharedLds sp, uint32_t c, uint32_t nseg) {
-  const Dev& d = *(const Dev*)dp;
-  const Shared& S = *(const Shared*)sp;
-  // one sigma for all ranges and one for all bearings (what the reference's model holds,
-  // range_bearing_model.hpp:21-117) -> no per-reading loads of them
-  // Two readings per lane per group: the two atan2 of a reading make this stream VALU-heavy (about
-  // 200 fp64 instructions per reading), so deeper groups buy nothing (one per lane: -4 %) and four
-  // per lane spill (-50 %).
-  if (d.usig_inv > 0.0 && d.ubsig_inv > 0.0) return RatioStream<true, true, 2>(d, c, S, nseg).run();
-  return RatioStream<false, true, 2>(d, c, S, nseg).run();
-}
-
 // Landmark edge (mcmc_slam.hpp:468-474): every reading of landmark f seen so
 // far, old estimate against `e_new`, both relative to the parent pose.
+template <bool RB>
 MG_DEV double eval_feature_edge(const Dev& d, uint32_t c, Shared& S, uint32_t f, const Vec2& e_new,
                                 unsigned long long& units) {
   const size_t fi = size_t(c) * d.Fcap + f;
@@ -589,7 +676,7 @@ MG_DEV double eval_feature_edge(const Dev& d, uint32_t c, Shared& S, uint32_t f,
   }
   __syncthreads();
   units += S.segpre[1];
-  const double acc = eval_ratio(d, c, S, 1);
+  const double acc = eval_ratio<RB>(d, c, S, 1);
   return block_sum(acc, S);
 }
 
@@ -628,6 +715,7 @@ MG_DEV uint32_t split_readings(const Dev& d, uint32_t lo, uint32_t hi, uint32_t 
 // readings taken up to t are affected; otherwise the landmark stays and the
 // readings after t are affected.  Either way the affected readings compare
 // |w_new - t_s| with |w_old - t_s| on the UNCHANGED pose table.
+template <bool RB>
 MG_DEV double eval_state_edge(const Dev& d, uint32_t c, Shared& S, uint32_t t, const Pose& q, uint32_t nf,
                               unsigned long long& units) {
   const uint32_t tid = threadIdx.x, nthr = blockDim.x;
@@ -695,7 +783,7 @@ MG_DEV double eval_state_edge(const Dev& d, uint32_t c, Shared& S, uint32_t t, c
       MG_STAMP(tc0);
       MG_PHASE_ADD(S, 1, tab, tc0);
       // C: stream the affected readings
-      acc += eval_ratio(d, c, S, nseg);
+      acc += eval_ratio<RB>(d, c, S, nseg);
       __syncthreads();
       MG_STAMP(tc1);
       MG_PHASE_ADD(S, 2, tc0, tc1);
@@ -1122,6 +1210,7 @@ MG_PIECE void piece_driver_advance(DevArgs dp, SharedLds sp, uint32_t c) {
   driver_advance(*(const Dev*)dp, c, *(Shared*)sp);
 }
 
+template <bool RB>
 MG_PIECE double piece_eval(DevArgs dp, SharedLds sp, uint32_t c, int op, uint32_t idx, double qx, double qy,
                            double qth, uint32_t nf) {
   const Dev& d = *(const Dev*)dp;
@@ -1129,9 +1218,9 @@ MG_PIECE double piece_eval(DevArgs dp, SharedLds sp, uint32_t c, int op, uint32_
   unsigned long long units = 0;
   double r;
   if (op == OP_EVAL_STATE)
-    r = eval_state_edge(d, c, S, idx, Pose{qx, qy, qth}, nf, units);
+    r = eval_state_edge<RB>(d, c, S, idx, Pose{qx, qy, qth}, nf, units);
   else
-    r = eval_feature_edge(d, c, S, idx, Vec2{qx, qy}, units);
+    r = eval_feature_edge<RB>(d, c, S, idx, Vec2{qx, qy}, units);
   if (threadIdx.x == 0) {
     S.n_units += units;
     if (op == OP_EVAL_STATE) ++S.n_state;
@@ -1181,6 +1270,7 @@ __global__ void advance_kernel(Dev d, uint32_t first_tn, uint32_t Tcur0, uint32_
   const DevArgs dp = (DevArgs)__builtin_amdgcn_kernarg_segment_ptr();
   const SharedLds sp = (SharedLds)&S;
   const uint32_t c = blockIdx.x;
+  const bool bearings = d.obear != nullptr;
   chain_state_load(d, c, S);
   if (threadIdx.x == 0) {
     S.Tcur = Tcur0;
@@ -1205,7 +1295,8 @@ __global__ void advance_kernel(Dev d, uint32_t first_tn, uint32_t Tcur0, uint32_
     const uint32_t idx = S.idx;
     const double qx = S.q[0], qy = S.q[1], qth = S.q[2];
     const uint32_t Tcur = S.Tcur, nf = S.nf;
-    const double r = piece_eval(dp, sp, c, op, idx, qx, qy, qth, nf);
+    const double r = bearings ? piece_eval<true>(dp, sp, c, op, idx, qx, qy, qth, nf)
+                              : piece_eval<false>(dp, sp, c, op, idx, qx, qy, qth, nf);
     MG_STAMP(te1);
     if (op != OP_EVAL_STATE) MG_PHASE_ADD(S, 3, td1, te1);
     if (threadIdx.x == 0) piece_finish_update(dp, sp, c, idx, r);
@@ -1534,7 +1625,8 @@ __global__ void eval_kernel(Dev d_by_value, uint32_t c, int kind, uint32_t idx, 
   double r;
   if (kind == MCMCGPU_STATE_EDGE) {
     const Pose q{q0, q1, q2};
-    r = eval_state_edge(d, c, S, idx, q, d.nf[c], units);
+    r = d.obear ? eval_state_edge<true>(d, c, S, idx, q, d.nf[c], units)
+                : eval_state_edge<false>(d, c, S, idx, q, d.nf[c], units);
     if (threadIdx.x == 0) {
       double mu[3], sd[3];
       load_control(d, idx, mu, sd);
@@ -1543,7 +1635,8 @@ __global__ void eval_kernel(Dev d_by_value, uint32_t c, int kind, uint32_t idx, 
       r = (control_log_pdf(mu, sd, q) - control_log_pdf(mu, sd, cur)) + r;
     }
   } else {
-    r = eval_feature_edge(d, c, S, idx, Vec2{q0, q1}, units);
+    r = d.obear ? eval_feature_edge<true>(d, c, S, idx, Vec2{q0, q1}, units)
+                : eval_feature_edge<false>(d, c, S, idx, Vec2{q0, q1}, units);
   }
   if (threadIdx.x == 0) *out = r;
 }

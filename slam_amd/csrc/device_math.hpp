@@ -66,7 +66,9 @@ MG_DEV Vec2 act_inverse(const Pose& p, const Vec2& v) {
 }
 
 MG_DEV double wrap_angle(double a) {
-  a = fmod(a, kTwoPi);
+  // fmod leaves an argument below the modulus as it is; almost every angle here is one, and the
+  // general fmod is a long loop on this hardware
+  if (!(fabs(a) < kTwoPi)) a = fmod(a, kTwoPi);
   if (a < -kPi)
     a += kTwoPi;
   else if (a >= kPi)

@@ -45,8 +45,10 @@ struct mcmcgpu_ctx {
   bool bearings_loaded = false;        // range-and-bearing handles: set_bearings done for the current problem
   std::vector<uint32_t> h_foff, h_ot;  // host copies of the landmark-major index
   std::vector<double> h_omu;
-  std::vector<EventPair> timings;
-  std::vector<EventPair> free_events;
+  std::vector<EventPair> timings;      // launches not yet folded into the totals below
+  std::vector<EventPair> free_events;  // pairs ready for reuse
+  double timed_ms = 0.0;               // finished launches already folded (see fold_timings)
+  uint32_t timed_launches = 0;
   // report records of the last mcmcgpu_run_reported that used the library's own buffer
   mcmcgpu_chain_summary* reports = nullptr;  // [kMaxOwnReports][max_chains]
   uint32_t report_intervals = 0;
@@ -112,6 +114,67 @@ int check_device_flags(mcmcgpu_handle h) {
     if (flags[c])
       return fail(h, MCMCGPU_ERR_DEVICE_FAULT,
                   "chain " + std::to_string(c) + " stopped: edge selection did not terminate");
+  return 0;
+}
+
+constexpr size_t kMaxPendingTimings = 1024;
+
+// Adds the durations of finished launches to the handle's totals and frees their event pairs for
+// reuse; with `wait` the stream is drained first so that every launch is finished.  Keeps a caller
+// that never asks for mcmcgpu_kernel_time (an online replay of 100 000 timesteps, one launch each)
+// from holding an event pair per launch.
+int fold_timings(mcmcgpu_handle h, bool wait) {
+  if (wait) HIP_TRY(h, hipStreamSynchronize(h->stream));
+  size_t kept = 0;
+  for (size_t i = 0; i < h->timings.size(); ++i) {
+    const EventPair ev = h->timings[i];
+    // launches finish in stream order: after the first unfinished one nothing later is done either
+    if (kept == 0 && (wait || hipEventQuery(ev.stop) == hipSuccess)) {
+      float ms = 0.f;
+      HIP_TRY(h, hipEventElapsedTime(&ms, ev.start, ev.stop));
+      h->timed_ms += ms;
+      ++h->timed_launches;
+      h->free_events.push_back(ev);
+    } else {
+      h->timings[kept++] = ev;
+    }
+  }
+  h->timings.resize(kept);
+  return 0;
+}
+
+// An event pair for one timed launch, `start` already recorded on the stream.
+int begin_timed(mcmcgpu_handle h, EventPair* ev) {
+  if (h->timings.size() >= kMaxPendingTimings)
+    if (int rc = fold_timings(h, false)) return rc;
+  if (!h->free_events.empty()) {
+    *ev = h->free_events.back();
+    h->free_events.pop_back();
+  } else {
+    HIP_TRY(h, hipEventCreate(&ev->start));
+    hipError_t e = hipEventCreate(&ev->stop);
+    if (e != hipSuccess) {
+      (void)hipEventDestroy(ev->start);
+      return fail(h, MCMCGPU_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e));
+    }
+  }
+  hipError_t e = hipEventRecord(ev->start, h->stream);
+  if (e != hipSuccess) {
+    h->free_events.push_back(*ev);
+    return fail(h, MCMCGPU_ERR_HIP, std::string("hipEventRecord: ") + hipGetErrorString(e));
+  }
+  return 0;
+}
+
+// Closes a timed launch: records `stop` when the launches went out (launch_error == hipSuccess),
+// gives the pair back otherwise.
+int end_timed(mcmcgpu_handle h, const EventPair& ev, hipError_t launch_error, const char* what) {
+  if (launch_error == hipSuccess) launch_error = hipEventRecord(ev.stop, h->stream);
+  if (launch_error != hipSuccess) {
+    h->free_events.push_back(ev);
+    return fail(h, MCMCGPU_ERR_HIP, std::string(what) + ": " + hipGetErrorString(launch_error));
+  }
+  h->timings.push_back(ev);
   return 0;
 }
 
@@ -439,19 +502,10 @@ int mcmcgpu_advance(mcmcgpu_handle h, uint32_t upto, uint32_t steps_per_timestep
   const bool grow = upto + 1 > h->next_timestep;
   if (!grow && end_steps == 0) return 0;
   EventPair ev;
-  if (!h->free_events.empty()) {
-    ev = h->free_events.back();
-    h->free_events.pop_back();
-  } else {
-    HIP_TRY(h, hipEventCreate(&ev.start));
-    HIP_TRY(h, hipEventCreate(&ev.stop));
-  }
-  HIP_TRY(h, hipEventRecord(ev.start, h->stream));
+  if (int rc = begin_timed(h, &ev)) return rc;
   hipLaunchKernelGGL(advance_kernel, dim3(h->chains), dim3(h->nthreads), 0, h->stream, h->d, h->next_timestep,
                      edges_grown(h), upto, steps_per_timestep, end_steps, grow ? 1u : 0u);
-  HIP_TRY(h, hipGetLastError());
-  HIP_TRY(h, hipEventRecord(ev.stop, h->stream));
-  h->timings.push_back(ev);
+  if (int rc = end_timed(h, ev, hipGetLastError(), "advance_kernel")) return rc;
   if (grow) h->next_timestep = upto + 1;
   return 0;
 }
@@ -562,14 +616,8 @@ int mcmcgpu_run_split(mcmcgpu_handle h, uint32_t steps, uint32_t slices) {
   const uint32_t T = edges_grown(h), C = h->chains;
   const uint32_t fblocks = std::max<uint32_t>(1, (h->d.F + 255) / 256);
   EventPair ev;  // the whole sequence counts as one timed launch (mcmcgpu_kernel_time)
-  if (!h->free_events.empty()) {
-    ev = h->free_events.back();
-    h->free_events.pop_back();
-  } else {
-    HIP_TRY(h, hipEventCreate(&ev.start));
-    HIP_TRY(h, hipEventCreate(&ev.stop));
-  }
-  HIP_TRY(h, hipEventRecord(ev.start, h->stream));
+  if (int rc = begin_timed(h, &ev)) return rc;
+  hipError_t launch_error = hipSuccess;
   // ends(begin 1) | setup, scan, eval, ends(finish k, begin k+1) | ... : 1 + 4 * steps launches
   if (steps) hipLaunchKernelGGL(split_ends_kernel, dim3(C), dim3(256), 0, h->stream, h->d, T, slices, 0u, 1u);
   for (uint32_t i = 0; i < steps; ++i) {
@@ -580,11 +628,9 @@ int mcmcgpu_run_split(mcmcgpu_handle h, uint32_t steps, uint32_t slices) {
     else
       hipLaunchKernelGGL(split_eval_kernel, dim3(slices, C), dim3(256), 0, h->stream, h->d);
     hipLaunchKernelGGL(split_ends_kernel, dim3(C), dim3(256), 0, h->stream, h->d, T, slices, 1u, i + 1 < steps ? 1u : 0u);
-    HIP_TRY(h, hipGetLastError());
+    if ((launch_error = hipGetLastError()) != hipSuccess) break;
   }
-  HIP_TRY(h, hipEventRecord(ev.stop, h->stream));
-  h->timings.push_back(ev);
-  return 0;
+  return end_timed(h, ev, launch_error, "split-mode launch");
 }
 
 int mcmcgpu_get_reports(mcmcgpu_handle h, mcmcgpu_chain_summary* out, uint32_t capacity, uint32_t* intervals) {
@@ -957,7 +1003,7 @@ int mcmcgpu_import_state(mcmcgpu_handle h, uint32_t chain, const void* dev_in, d
   HIP_TRY(h, cp(d.fey + size_t(chain) * d.Fcap, in + 3 * T + F, F));
   HIP_TRY(h, hipMemcpyAsync(d.ll + chain, &log_likelihood, sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
-  HIP_TRY(h, rebuild_impl(h) == 0 ? hipSuccess : hipErrorUnknown);
+  if (int rc = rebuild_impl(h)) return rc;
   hipLaunchKernelGGL(reweigh_kernel, dim3(1), dim3(256), 0, h->stream, d, chain, uint32_t(T));
   HIP_TRY(h, hipGetLastError());
   return 0;
@@ -1021,18 +1067,12 @@ int mcmcgpu_sync(mcmcgpu_handle h) {
 int mcmcgpu_kernel_time(mcmcgpu_handle h, double* avg_ms, uint32_t* launches) {
   if (!h) return MCMCGPU_ERR_ARGUMENT;
   HIP_TRY(h, hipSetDevice(h->cfg.device));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
-  double total = 0.0;
-  for (auto& ev : h->timings) {
-    float ms = 0.f;
-    HIP_TRY(h, hipEventElapsedTime(&ms, ev.start, ev.stop));
-    total += ms;
-    h->free_events.push_back(ev);
-  }
-  const uint32_t n = uint32_t(h->timings.size());
-  h->timings.clear();
-  if (avg_ms) *avg_ms = n ? total / n : 0.0;
+  if (int rc = fold_timings(h, true)) return rc;
+  const uint32_t n = h->timed_launches;
+  if (avg_ms) *avg_ms = n ? h->timed_ms / n : 0.0;
   if (launches) *launches = n;
+  h->timed_ms = 0.0;
+  h->timed_launches = 0;
   return 0;
 }
 
