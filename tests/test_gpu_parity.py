@@ -720,3 +720,59 @@ def test_range_bearing_with_a_sigma_per_reading(split):
         compare_traces(g.trace(c), w.trace(c), abs(w.log_likelihood(c)))
         assert_close(ll[c], w.log_likelihood(c), REL, f"chain {c} final log likelihood")
         assert_close(full[c], w.full_log_likelihood(c), REL, f"chain {c} full log likelihood")
+
+
+def _thinned(p, rng, keep):
+    """A copy of problem `p` with a random subset of its readings: landmarks renumbered by first
+    appearance (what slam_data does), some timesteps left without readings, some landmarks seen once."""
+    sel = rng.random(p["N"]) < keep
+    if not sel.any():
+        sel[0] = True
+    q = dict(p)
+    t, f = p["obs_t"][sel], p["obs_f"][sel]
+    ids, first = {}, []
+    for x in f:
+        if int(x) not in ids:
+            ids[int(x)] = len(ids)
+            first.append(int(x))
+    q["obs_t"] = np.ascontiguousarray(t)
+    q["obs_f"] = np.array([ids[int(x)] for x in f], dtype=p["obs_f"].dtype)
+    q["obs_mean"] = np.ascontiguousarray(p["obs_mean"][sel])
+    q["obs_std"] = np.ascontiguousarray(p["obs_std"][sel])
+    q["N"], q["F"] = int(sel.sum()), len(ids)
+    return q
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_random_small_problems_match_oracle(case):
+    """A sweep over small random shapes -- 1 to 90 timesteps, 1 to 9 landmarks, 15 to 100 % of the
+    readings kept, 0 to 3 updates per timestep, both draw orders, 64 to 256 lanes -- each replayed
+    online and compared with the oracle step for step."""
+    rng = np.random.default_rng(1000 + case)
+    T = int(rng.integers(1, 91))
+    F = int(rng.integers(1, 10))
+    p = synthetic.make_problem(T=T, n_landmarks=F, k_nearest=int(rng.integers(1, F + 1)), seed=int(rng.integers(1, 1 << 20)),
+                               lap_steps=int(rng.integers(20, 120)), wobble_period=500, range_stddev=2.0,
+                               landmark_spread=6.0)
+    p = _thinned(p, rng, keep=float(rng.uniform(0.15, 1.0)))
+    per_ts, end_steps = int(rng.integers(0, 4)), int(rng.integers(0, 120))
+    uniform_first = bool(rng.integers(0, 2))
+    lanes = int(rng.choice([64, 128, 256]))
+    seeds = capi.seed_sequence(77 + case, 2)
+    w = oracle_lib.World()
+    w.set_input(p["ctrl_mean"], p["ctrl_std"], p["obs_t"], p["obs_f"], p["obs_mean"], p["obs_std"])
+    for s in seeds:
+        w.add_chain(int(s), steps_per_timestep=per_ts, end_steps=end_steps, uniform_first=uniform_first, trace=True)
+    w.replay(p["T"], finish=True)
+    g = gpu_handle(p, seeds, trace_capacity=4096, feature_uniform_first=uniform_first, threads_per_chain=lanes)
+    g.advance(p["T"], steps_per_timestep=per_ts, end_steps=end_steps)
+    g.sync()
+    ll, full = g.log_likelihood(), g.full_log_likelihood()
+    for c in range(len(seeds)):
+        compare_traces(g.trace(c), w.trace(c), max(abs(w.log_likelihood(c)), 1.0))
+        assert_close(ll[c], w.log_likelihood(c), REL, f"chain {c} final log likelihood")
+        assert_close(full[c], w.full_log_likelihood(c), REL, f"chain {c} from-scratch log likelihood")
+        so, sg = w.state(c), g.get_state(c)
+        assert np.array_equal(sg["feat_parent"], so["feat_parent"])
+        assert_close(sg["cum"], so["cum"], REL, "cumulative poses")
+        assert_close(sg["feat_est"], so["feat_est"], REL, "landmark estimates")
