@@ -99,6 +99,22 @@ int mcmcgpu_upload_problem(mcmcgpu_handle h, uint32_t T, const double* ctrl_mean
                            uint32_t N, const uint32_t* obs_timestep, const uint32_t* obs_feature,
                            const double* obs_mean, const double* obs_stddev, uint32_t F);
 
+/* Online growth, one timestep at a time: what slam_data::add_control / add_observation hand to
+ * the listeners before timestep_listener::timestep(t) (src/slam/slam_data.hpp:76-101,
+ * mcmc_slam.hpp:272-336), without uploading the problem again.  Appends the control of the edge to
+ * the new timestep (3 + 3 doubles; NULL for timestep 0 of an empty problem, which has none) and the
+ * n_obs readings taken there (obs_feature as in mcmcgpu_upload_problem: a landmark seen for the
+ * first time has the next unused index; bearing arrays only on a range-and-bearing handle).
+ * init_state_rel (3 doubles) and init_feat_rel (2 doubles per landmark that is NEW in this call,
+ * in order of appearance) continue the arrays of mcmcgpu_set_initial_estimates when they reach
+ * exactly up to the new edge / landmark; NULL = none.  The readings go into free slots next to
+ * their landmark's list; when a list is full the library lays the problem out again with twice
+ * the room (amortised O(1) per reading).  Follow with mcmcgpu_grow / mcmcgpu_advance. */
+int mcmcgpu_append_timestep(mcmcgpu_handle h, const double* ctrl_mean, const double* ctrl_stddev, uint32_t n_obs,
+                            const uint32_t* obs_feature, const double* obs_mean, const double* obs_stddev,
+                            const double* bearing_mean, const double* bearing_stddev, const double* init_state_rel,
+                            const double* init_feat_rel);
+
 /* Range-and-bearing handles only: the bearing half of every reading's model
  * (range_bearing_model::builder, range_bearing_model.hpp:100-116), in the
  * ARRIVAL order of the mcmcgpu_upload_problem call it follows; required after

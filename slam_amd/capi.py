@@ -51,6 +51,7 @@ EXPORTS = [
     "mcmcgpu_create",
     "mcmcgpu_destroy",
     "mcmcgpu_upload_problem",
+    "mcmcgpu_append_timestep",
     "mcmcgpu_set_bearings",
     "mcmcgpu_init_chains",
     "mcmcgpu_set_initial_estimates",
@@ -194,6 +195,20 @@ class McmcGpu:
             self.lib.mcmcgpu_upload_problem(self.h, ctypes.c_uint32(cm.shape[0]), _ptr(cm), _ptr(cs),
                                             ctypes.c_uint32(ot.size), _ptr(ot), _ptr(of), _ptr(om), _ptr(os_),
                                             ctypes.c_uint32(F)), "mcmcgpu_upload_problem")
+
+    def append_timestep(self, ctrl_mean=None, ctrl_std=None, obs_f=(), obs_mean=(), obs_std=(), bearing_mean=None,
+                        bearing_std=None, init_state_rel=None, init_feat_rel=None):
+        """One more timestep: its control (None for timestep 0 of an empty problem) and the readings taken there."""
+        def arr(x, dt):
+            return None if x is None else np.ascontiguousarray(x, dtype=dt)
+        cm, cs = arr(ctrl_mean, np.float64), arr(ctrl_std, np.float64)
+        of, om, os_ = arr(obs_f, np.uint32), arr(obs_mean, np.float64), arr(obs_std, np.float64)
+        bm, bs = arr(bearing_mean, np.float64), arr(bearing_std, np.float64)
+        ir, if_ = arr(init_state_rel, np.float64), arr(init_feat_rel, np.float64)
+        self._check(
+            self.lib.mcmcgpu_append_timestep(self.h, _ptr(cm), _ptr(cs), ctypes.c_uint32(of.size), _ptr(of), _ptr(om),
+                                             _ptr(os_), _ptr(bm), _ptr(bs), _ptr(ir), _ptr(if_)),
+            "mcmcgpu_append_timestep")
 
     def set_bearings(self, bearing_mean, bearing_std):
         """The bearing half of every reading (arrival order); range-and-bearing handles, after every upload."""

@@ -1808,6 +1808,61 @@ __global__ void full_ll_kernel(Dev d, uint32_t first, uint32_t Tcur, double* out
   if (tid == 0) out[c] = r;
 }
 
+// One appended timestep (or a piece of one), handed over as kernel arguments: the new control and
+// up to kAppendMax readings with the slots the host has chosen for them.  Writes what
+// mcmcgpu_upload_problem would have put there, in place; the arrays are read-only for every other
+// kernel, so the const is cast away here and nowhere else.
+constexpr int kAppendMax = 16;
+struct AppendArgs {
+  uint32_t t;            // timestep of the readings (and of the pose the control leads to)
+  uint32_t has_control;  // control of edge t-1 -> t is in cm / cs
+  double cm[3], cs[3];
+  uint32_t has_init_rel;  // initial estimate of that edge is in irel (set_initialiser)
+  double irel[3];
+  uint32_t n;             // readings in this piece
+  uint32_t arrival0;      // arrival index of the first of them
+  uint32_t arrivals_end;  // arrival index one past the last reading of timestep t so far
+  uint32_t slot[kAppendMax], f[kAppendMax];
+  uint32_t is_new[kAppendMax];    // first reading of its landmark
+  uint32_t has_ifeat[kAppendMax];  // an initial estimate for that new landmark is in ifeat
+  double mu[kAppendMax], sd[kAppendMax], bmu[kAppendMax], bsd[kAppendMax];
+  double ifeat[kAppendMax][2];
+};
+__global__ void append_kernel(Dev d, AppendArgs a) {
+  const uint32_t i = threadIdx.x;
+  if (i == 0) {
+    if (a.has_control) {
+      for (int k = 0; k < 3; ++k) {
+        const_cast<double*>(d.cmu)[size_t(k) * d.Tcap + (a.t - 1)] = a.cm[k];
+        const_cast<double*>(d.csd)[size_t(k) * d.Tcap + (a.t - 1)] = a.cs[k];
+        if (a.has_init_rel) const_cast<double*>(d.init_rel)[3 * size_t(a.t - 1) + k] = a.irel[k];
+      }
+    }
+    const_cast<uint32_t*>(d.toff)[a.t + 1] = a.arrivals_end;
+  }
+  if (i < a.n) {
+    const uint32_t s = a.slot[i], f = a.f[i];
+    const_cast<ObsRec*>(d.orec)[s] = ObsRec{a.mu[i], a.t, f};
+    const_cast<double*>(d.osd)[s] = a.sd[i];
+    const_cast<double*>(d.oisd)[s] = 1.0 / a.sd[i];
+    if (d.obear) {
+      const_cast<double*>(d.obear)[s] = a.bmu[i];
+      const_cast<double*>(d.obsd)[s] = a.bsd[i];
+      const_cast<double*>(d.obisd)[s] = 1.0 / a.bsd[i];
+    }
+    const_cast<uint32_t*>(d.tobs)[a.arrival0 + i] = s;
+    if ((s & 31u) == 0) const_cast<uint32_t*>(d.opiv)[s >> 5] = a.t;
+    if (a.is_new[i]) {
+      const_cast<uint32_t*>(d.foff)[f] = s;
+      const_cast<uint32_t*>(d.ffirst)[f] = a.t;
+      if (a.has_ifeat[i]) {
+        const_cast<double*>(d.init_feat)[2 * size_t(f)] = a.ifeat[i][0];
+        const_cast<double*>(d.init_feat)[2 * size_t(f) + 1] = a.ifeat[i][1];
+      }
+    }
+  }
+}
+
 __global__ void init_chains_kernel(Dev d, const uint32_t* seeds) {
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= d.C) return;

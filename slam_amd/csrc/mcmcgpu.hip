@@ -41,10 +41,20 @@ struct mcmcgpu_ctx {
   uint32_t chains = 0;
   bool problem_loaded = false;
   uint32_t next_timestep = 0;  // first timestep the chains have not processed
-  std::vector<uint32_t> h_tobs;        // arrival order -> landmark-major position
-  bool bearings_loaded = false;        // range-and-bearing handles: set_bearings done for the current problem
-  std::vector<uint32_t> h_foff, h_ot;  // host copies of the landmark-major index
-  std::vector<double> h_omu;
+  bool bearings_loaded = false;  // range-and-bearing handles: every reading of the current problem has its bearing
+  // The problem as it was given, in arrival order: kept for re-layouts (see lay_out) and appends.
+  std::vector<double> a_cmean, a_cstd;  // [T][3]
+  std::vector<uint32_t> a_t, a_f;       // [N]
+  std::vector<double> a_mean, a_sd, a_bmean, a_bsd;
+  // Landmark-major slots on the device: landmark f owns slots [f_start[f], f_start[f] + f_cap[f]), the
+  // first f_count[f] of them filled, in time order.  A compact layout has f_cap == f_count; after an
+  // append has outgrown it, capacities are doubled so that most appends write one slot in place.
+  std::vector<uint32_t> f_start, f_count, f_cap;
+  uint32_t slots_used = 0;
+  std::vector<uint32_t> h_tobs;  // arrival order -> slot
+  std::vector<uint32_t> h_ot;    // slot -> timestep (filled slots)
+  std::vector<double> h_omu;     // slot -> measured range
+  double sigma_all = 0.0, bsigma_all = 0.0;  // the one sigma every range / bearing has so far, or 0
   std::vector<EventPair> timings;      // launches not yet folded into the totals below
   std::vector<EventPair> free_events;  // pairs ready for reuse
   double timed_ms = 0.0;               // finished launches already folded (see fold_timings)
@@ -178,6 +188,104 @@ int end_timed(mcmcgpu_handle h, const EventPair& ev, hipError_t launch_error, co
   return 0;
 }
 
+// Places the problem held in the handle's arrival-order arrays into landmark-major slots and
+// uploads everything.  with_slack: every landmark gets room for twice its readings (at least 32
+// slots) as far as the slot capacity allows, so that later appends find a free slot next to
+// their landmark's list.  Chain state refers to readings by their rank inside a landmark's list,
+// never by slot, so chains that have already grown survive a new layout.
+int lay_out(mcmcgpu_handle h, bool with_slack) {
+  Dev& d = h->d;
+  const uint32_t T = uint32_t(h->a_cmean.size() / 3), N = uint32_t(h->a_t.size()), F = uint32_t(h->f_count.size());
+  h->f_cap = h->f_count;
+  if (with_slack) {
+    uint64_t want = 0;
+    for (uint32_t f = 0; f < F; ++f) want += std::max<uint32_t>(32, 2 * h->f_count[f]);
+    if (want <= d.Ncap) {
+      for (uint32_t f = 0; f < F; ++f) h->f_cap[f] = std::max<uint32_t>(32, 2 * h->f_count[f]);
+    } else {  // share what is left evenly
+      const uint32_t extra = F ? (d.Ncap - N) / F : 0;
+      for (uint32_t f = 0; f < F; ++f) h->f_cap[f] = h->f_count[f] + extra;
+    }
+  }
+  h->f_start.assign(size_t(F) + 1, 0);
+  for (uint32_t f = 0; f < F; ++f) h->f_start[f + 1] = h->f_start[f] + h->f_cap[f];
+  const uint32_t S = h->f_start[F];  // slots in use, gaps included
+  h->slots_used = S;
+  // controls: [t][3] -> [3][Tcap]
+  std::vector<double> row(T);
+  auto up = [&](const void* dst, const void* src, size_t bytes) {
+    return bytes ? hipMemcpyAsync(const_cast<void*>(dst), src, bytes, hipMemcpyHostToDevice, h->stream) : hipSuccess;
+  };
+  for (int i = 0; i < 3; ++i) {
+    for (uint32_t t = 0; t < T; ++t) row[t] = h->a_cmean[3 * size_t(t) + i];
+    HIP_TRY(h, up(d.cmu + size_t(i) * d.Tcap, row.data(), size_t(T) * sizeof(double)));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));  // `row` is reused
+    for (uint32_t t = 0; t < T; ++t) row[t] = h->a_cstd[3 * size_t(t) + i];
+    HIP_TRY(h, up(d.csd + size_t(i) * d.Tcap, row.data(), size_t(T) * sizeof(double)));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  }
+  // readings: arrival order -> slots, time-sorted inside a landmark
+  std::vector<uint32_t> toff(size_t(T) + 2, 0), fill(h->f_start.begin(), h->f_start.end() - 1), tobs(N), ffirst(F, 0),
+      opiv(size_t(S) / 32 + 1, 0);
+  h->h_ot.assign(S, 0);
+  h->h_omu.assign(S, 0.0);
+  std::vector<ObsRec> orec(S, ObsRec{0.0, 0, 0});
+  std::vector<double> oisd(S, 1.0), osd(S, 1.0);
+  bool uniform_sigma = N > 0;
+  for (uint32_t i = 0; i < N; ++i) {
+    const uint32_t f = h->a_f[i], t = h->a_t[i];
+    const uint32_t pos = fill[f]++;
+    if (pos == h->f_start[f]) ffirst[f] = t;
+    ++toff[t + 1];
+    h->h_ot[pos] = t;
+    h->h_omu[pos] = h->a_mean[i];
+    osd[pos] = h->a_sd[i];
+    oisd[pos] = 1.0 / h->a_sd[i];
+    orec[pos] = ObsRec{h->a_mean[i], t, f};
+    tobs[i] = pos;  // arrivals are already grouped by timestep, in order
+    uniform_sigma = uniform_sigma && h->a_sd[i] == h->a_sd[0];
+  }
+  for (uint32_t t = 0; t <= T; ++t) toff[t + 1] += toff[t];
+  for (size_t i = 0; 32 * i < S; ++i) opiv[i] = h->h_ot[32 * i];
+  HIP_TRY(h, up(d.foff, h->f_start.data(), h->f_start.size() * sizeof(uint32_t)));
+  HIP_TRY(h, up(d.toff, toff.data(), toff.size() * sizeof(uint32_t)));
+  HIP_TRY(h, up(d.orec, orec.data(), size_t(S) * sizeof(ObsRec)));
+  HIP_TRY(h, up(d.oisd, oisd.data(), size_t(S) * sizeof(double)));
+  HIP_TRY(h, up(d.opiv, opiv.data(), opiv.size() * sizeof(uint32_t)));
+  HIP_TRY(h, up(d.tobs, tobs.data(), size_t(N) * sizeof(uint32_t)));
+  HIP_TRY(h, up(d.osd, osd.data(), size_t(S) * sizeof(double)));
+  HIP_TRY(h, up(d.ffirst, ffirst.data(), size_t(F) * sizeof(uint32_t)));
+  std::vector<double> bmu, bsd, bisd;
+  bool uniform_bsigma = false;
+  if (h->cfg.range_bearing && h->a_bmean.size() == N && N) {
+    bmu.assign(S, 0.0);
+    bsd.assign(S, 1.0);
+    bisd.assign(S, 1.0);
+    uniform_bsigma = true;
+    for (uint32_t i = 0; i < N; ++i) {
+      const uint32_t pos = tobs[i];
+      bmu[pos] = h->a_bmean[i];
+      bsd[pos] = h->a_bsd[i];
+      bisd[pos] = 1.0 / h->a_bsd[i];
+      uniform_bsigma = uniform_bsigma && h->a_bsd[i] == h->a_bsd[0];
+    }
+    HIP_TRY(h, up(d.obear, bmu.data(), size_t(S) * sizeof(double)));
+    HIP_TRY(h, up(d.obsd, bsd.data(), size_t(S) * sizeof(double)));
+    HIP_TRY(h, up(d.obisd, bisd.data(), size_t(S) * sizeof(double)));
+  }
+  HIP_TRY(h, hipStreamSynchronize(h->stream));  // host staging vectors die here
+  d.T = T;
+  d.N = N;
+  d.F = F;
+  h->sigma_all = uniform_sigma ? h->a_sd[0] : 0.0;
+  d.usig_inv = uniform_sigma ? 1.0 / h->a_sd[0] : 0.0;
+  h->bsigma_all = uniform_bsigma ? h->a_bsd[0] : 0.0;
+  d.ubsig_inv = uniform_bsigma ? 1.0 / h->a_bsd[0] : 0.0;
+  h->h_tobs = tobs;
+  h->problem_loaded = true;
+  return 0;
+}
+
 int rebuild_impl(mcmcgpu_handle h) {
   const uint32_t Tcur = edges_grown(h);
   const uint32_t ntiles = std::max<uint32_t>(1, (Tcur + (1u << kTileShift) - 1) >> kTileShift);
@@ -205,6 +313,11 @@ int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(nullptr, MCMCGPU_ERR_HIP, "no HIP device available (this library has no CPU path)");
   if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, MCMCGPU_ERR_ARGUMENT, "device ordinal out of range");
+  // slots for readings: twice the readings plus a first allotment per landmark, so that appended
+  // readings find room next to their landmark's list (see lay_out)
+  const uint64_t slots = 2 * uint64_t(std::max<uint32_t>(cfg->max_observations, 1)) +
+                         32 * uint64_t(std::max<uint32_t>(cfg->max_features, 1));
+  if (slots > 0xFFFFFFFFull) return fail(nullptr, MCMCGPU_ERR_CAPACITY, "max_observations too large");
   hipError_t e = hipSetDevice(cfg->device);
   if (e != hipSuccess) return fail(nullptr, MCMCGPU_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
 
@@ -224,7 +337,7 @@ int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out) {
   Dev& d = h->d;
   d.Tcap = std::max<uint32_t>(cfg->max_timesteps, 1);
   d.Fcap = std::max<uint32_t>(cfg->max_features, 1);
-  d.Ncap = std::max<uint32_t>(cfg->max_observations, 1);
+  d.Ncap = uint32_t(slots);
   d.C = 0;
   d.NTcap = (d.Tcap >> kTileShift) + 1;
   d.uniform_first = cfg->feature_uniform_first ? 1 : 0;
@@ -339,82 +452,196 @@ int mcmcgpu_upload_problem(mcmcgpu_handle h, uint32_t T, const double* ctrl_mean
                            uint32_t N, const uint32_t* obs_timestep, const uint32_t* obs_feature,
                            const double* obs_mean, const double* obs_stddev, uint32_t F) {
   if (!h) return MCMCGPU_ERR_ARGUMENT;
-  Dev& d = h->d;
   if (T > h->cfg.max_timesteps || N > h->cfg.max_observations || F > h->cfg.max_features)
     return fail(h, MCMCGPU_ERR_CAPACITY, "problem exceeds the capacities given to mcmcgpu_create");
   if ((T && (!ctrl_mean || !ctrl_stddev)) || (N && (!obs_timestep || !obs_feature || !obs_mean || !obs_stddev)))
     return fail(h, MCMCGPU_ERR_ARGUMENT, "null problem array");
   if (T + 1 < h->next_timestep) return fail(h, MCMCGPU_ERR_STATE, "problem shorter than what the chains have processed");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
-
-  // controls: [t][3] -> [3][Tcap]
-  std::vector<double> cmu(3 * size_t(d.Tcap), 0.0), csd(3 * size_t(d.Tcap), 1.0);
-  for (uint32_t t = 0; t < T; ++t)
-    for (int i = 0; i < 3; ++i) {
-      cmu[size_t(i) * d.Tcap + t] = ctrl_mean[3 * size_t(t) + i];
-      csd[size_t(i) * d.Tcap + t] = ctrl_stddev[3 * size_t(t) + i];
-    }
-  // readings: arrival order -> landmark-major, time-sorted inside a landmark
-  std::vector<uint32_t> foff(size_t(F) + 1, 0), toff(size_t(T) + 2, 0);
+  // arrival order: non-decreasing timesteps, landmarks numbered by first appearance, at most one
+  // reading per landmark and timestep
   uint32_t seen = 0;
+  std::vector<uint32_t> last_t(F, 0);
   for (uint32_t i = 0; i < N; ++i) {
     const uint32_t f = obs_feature[i], t = obs_timestep[i];
     if (t > T) return fail(h, MCMCGPU_ERR_ARGUMENT, "reading " + std::to_string(i) + " has a timestep beyond T");
     if (i && t < obs_timestep[i - 1]) return fail(h, MCMCGPU_ERR_ARGUMENT, "readings are not in arrival order");
     if (f > seen || f >= F)
       return fail(h, MCMCGPU_ERR_ARGUMENT, "landmark indices must be dense and numbered by first appearance");
-    if (f == seen) ++seen;
+    if (f == seen)
+      ++seen;
+    else if (last_t[f] >= t)
+      return fail(h, MCMCGPU_ERR_ARGUMENT, "a landmark has two readings at one timestep");
+    last_t[f] = t;
     if (!(obs_stddev[i] > 0)) return fail(h, MCMCGPU_ERR_ARGUMENT, "non-positive reading stddev");
-    ++foff[f + 1];
-    ++toff[t + 1];
   }
   if (seen != F) return fail(h, MCMCGPU_ERR_ARGUMENT, "F does not match the landmarks that appear in the readings");
-  for (uint32_t f = 0; f < F; ++f) foff[f + 1] += foff[f];
-  for (uint32_t t = 0; t <= T; ++t) toff[t + 1] += toff[t];
-  std::vector<uint32_t> fill(foff.begin(), foff.end() - 1), ot(N), tobs(N), ffirst(F, 0), opiv(size_t(N) / 32 + 1, 0);
-  std::vector<ObsRec> orec(N);
-  std::vector<double> oisd(N);
-  std::vector<double> omu(N), osd(N);
-  for (uint32_t i = 0; i < N; ++i) {
-    const uint32_t f = obs_feature[i];
-    const uint32_t pos = fill[f]++;
-    if (pos > foff[f] && ot[pos - 1] >= obs_timestep[i])
-      return fail(h, MCMCGPU_ERR_ARGUMENT, "a landmark has two readings at one timestep");
-    if (pos == foff[f]) ffirst[f] = obs_timestep[i];
-    ot[pos] = obs_timestep[i];
-    omu[pos] = obs_mean[i];
-    osd[pos] = obs_stddev[i];
-    orec[pos] = ObsRec{obs_mean[i], obs_timestep[i], f};
-    oisd[pos] = 1.0 / obs_stddev[i];
-    tobs[i] = pos;  // arrivals are already grouped by timestep, in order
-  }
-  auto up = [&](const void* dst, const void* src, size_t bytes) {
-    return bytes ? hipMemcpyAsync(const_cast<void*>(dst), src, bytes, hipMemcpyHostToDevice, h->stream) : hipSuccess;
-  };
-  HIP_TRY(h, up(d.cmu, cmu.data(), cmu.size() * sizeof(double)));
-  HIP_TRY(h, up(d.csd, csd.data(), csd.size() * sizeof(double)));
-  HIP_TRY(h, up(d.foff, foff.data(), foff.size() * sizeof(uint32_t)));
-  HIP_TRY(h, up(d.toff, toff.data(), toff.size() * sizeof(uint32_t)));
-  for (size_t i = 0; 32 * i < N; ++i) opiv[i] = ot[32 * i];
-  bool uniform_sigma = N > 0;
-  for (uint32_t i = 1; i < N; ++i) uniform_sigma = uniform_sigma && obs_stddev[i] == obs_stddev[0];
-  HIP_TRY(h, up(d.orec, orec.data(), size_t(N) * sizeof(ObsRec)));
-  HIP_TRY(h, up(d.oisd, oisd.data(), size_t(N) * sizeof(double)));
-  HIP_TRY(h, up(d.opiv, opiv.data(), opiv.size() * sizeof(uint32_t)));
-  HIP_TRY(h, up(d.tobs, tobs.data(), size_t(N) * sizeof(uint32_t)));
-  HIP_TRY(h, up(d.osd, osd.data(), size_t(N) * sizeof(double)));
-  HIP_TRY(h, up(d.ffirst, ffirst.data(), size_t(F) * sizeof(uint32_t)));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));  // host staging vectors die here
-  d.T = T;
-  d.N = N;
-  d.F = F;
-  d.usig_inv = uniform_sigma ? 1.0 / obs_stddev[0] : 0.0;
-  h->h_tobs = tobs;
+  h->a_cmean.assign(ctrl_mean, ctrl_mean + 3 * size_t(T));
+  h->a_cstd.assign(ctrl_stddev, ctrl_stddev + 3 * size_t(T));
+  h->a_t.assign(obs_timestep, obs_timestep + N);
+  h->a_f.assign(obs_feature, obs_feature + N);
+  h->a_mean.assign(obs_mean, obs_mean + N);
+  h->a_sd.assign(obs_stddev, obs_stddev + N);
+  h->a_bmean.clear();
+  h->a_bsd.clear();
   h->bearings_loaded = false;
-  d.ubsig_inv = 0.0;
-  h->h_foff = foff;
-  h->h_ot = ot;
-  h->h_omu = omu;
+  h->f_count.assign(F, 0);
+  for (uint32_t i = 0; i < N; ++i) ++h->f_count[obs_feature[i]];
+  return lay_out(h, false);
+}
+
+int mcmcgpu_append_timestep(mcmcgpu_handle h, const double* ctrl_mean, const double* ctrl_stddev, uint32_t n_obs,
+                            const uint32_t* obs_feature, const double* obs_mean, const double* obs_stddev,
+                            const double* bearing_mean, const double* bearing_stddev, const double* init_state_rel,
+                            const double* init_feat_rel) {
+  if (!h) return MCMCGPU_ERR_ARGUMENT;
+  if ((ctrl_mean == nullptr) != (ctrl_stddev == nullptr)) return fail(h, MCMCGPU_ERR_ARGUMENT, "control mean and stddev go together");
+  if (n_obs && (!obs_feature || !obs_mean || !obs_stddev)) return fail(h, MCMCGPU_ERR_ARGUMENT, "null reading array");
+  const bool rb = h->cfg.range_bearing != 0;
+  if (rb && n_obs && (!bearing_mean || !bearing_stddev))
+    return fail(h, MCMCGPU_ERR_ARGUMENT, "a range-and-bearing handle needs the bearings of the appended readings");
+  Dev& d = h->d;
+  const uint32_t T0 = uint32_t(h->a_cmean.size() / 3), N0 = uint32_t(h->a_t.size()), F0 = uint32_t(h->f_count.size());
+  if (!ctrl_mean && (T0 != 0 || N0 != 0))
+    return fail(h, MCMCGPU_ERR_STATE, "only timestep 0 of an empty problem comes without a control");
+  if (rb && N0 && !h->bearings_loaded)
+    return fail(h, MCMCGPU_ERR_STATE, "mcmcgpu_set_bearings must follow mcmcgpu_upload_problem before readings are appended");
+  const uint32_t t = ctrl_mean ? T0 + 1 : 0;  // timestep of the appended readings
+  if (t > h->cfg.max_timesteps || uint64_t(N0) + n_obs > h->cfg.max_observations)
+    return fail(h, MCMCGPU_ERR_CAPACITY, "appended data exceeds the capacities given to mcmcgpu_create");
+  // the same checks mcmcgpu_upload_problem makes, for the new readings only
+  uint32_t F1 = F0;
+  for (uint32_t i = 0; i < n_obs; ++i) {
+    const uint32_t f = obs_feature[i];
+    if (f > F1) return fail(h, MCMCGPU_ERR_ARGUMENT, "landmark indices must be dense and numbered by first appearance");
+    if (f == F1) {
+      if (F1 + 1 > h->cfg.max_features) return fail(h, MCMCGPU_ERR_CAPACITY, "more landmarks than max_features");
+      ++F1;
+    } else if (f < F0) {
+      if (h->h_ot[h->f_start[f] + h->f_count[f] - 1] >= t)
+        return fail(h, MCMCGPU_ERR_ARGUMENT, "a landmark has two readings at one timestep");
+    }
+    for (uint32_t k = 0; k < i; ++k)
+      if (obs_feature[k] == f) return fail(h, MCMCGPU_ERR_ARGUMENT, "a landmark has two readings at one timestep");
+    if (!(obs_stddev[i] > 0) || (rb && !(bearing_stddev[i] > 0))) return fail(h, MCMCGPU_ERR_ARGUMENT, "non-positive reading stddev");
+  }
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  // initial estimates continue the arrays of mcmcgpu_set_initial_estimates only without a hole
+  const bool take_irel = init_state_rel && ctrl_mean && d.n_init_rel == T0;
+  const bool take_ifeat = init_feat_rel && d.n_init_feat == F0;
+  // does every reading find a free slot next to its landmark's list?
+  bool fits = h->problem_loaded || (T0 == 0 && N0 == 0);
+  std::vector<uint32_t> new_start(F1 - F0, 0);
+  uint32_t end = h->slots_used;
+  for (uint32_t i = 0; i < n_obs && fits; ++i) {
+    const uint32_t f = obs_feature[i];
+    if (f < F0) {
+      fits = h->f_count[f] < h->f_cap[f];
+    } else {  // a new landmark takes 32 slots at the end
+      fits = uint64_t(end) + 32 <= d.Ncap;
+      new_start[f - F0] = end;
+      end += 32;
+    }
+  }
+  // the arrival-order copy grows either way
+  if (ctrl_mean) {
+    h->a_cmean.insert(h->a_cmean.end(), ctrl_mean, ctrl_mean + 3);
+    h->a_cstd.insert(h->a_cstd.end(), ctrl_stddev, ctrl_stddev + 3);
+  }
+  for (uint32_t i = 0; i < n_obs; ++i) {
+    h->a_t.push_back(t);
+    h->a_f.push_back(obs_feature[i]);
+    h->a_mean.push_back(obs_mean[i]);
+    h->a_sd.push_back(obs_stddev[i]);
+    if (rb) {
+      h->a_bmean.push_back(bearing_mean[i]);
+      h->a_bsd.push_back(bearing_stddev[i]);
+    }
+  }
+  if (rb) h->bearings_loaded = true;
+  auto take_estimates = [&]() {  // into the arrays of mcmcgpu_set_initial_estimates
+    if (take_irel) {
+      HIP_TRY(h, hipMemcpyAsync(const_cast<double*>(d.init_rel) + 3 * size_t(T0), init_state_rel, 3 * sizeof(double),
+                                hipMemcpyHostToDevice, h->stream));
+      d.n_init_rel = T0 + 1;
+    }
+    if (take_ifeat && F1 > F0) {
+      HIP_TRY(h, hipMemcpyAsync(const_cast<double*>(d.init_feat) + 2 * size_t(F0), init_feat_rel,
+                                2 * size_t(F1 - F0) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+      d.n_init_feat = F1;
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return 0;
+  };
+  if (!fits) {  // a landmark's slots are used up (or nothing is laid out yet): new layout, with room to grow
+    h->f_count.resize(F1, 0);
+    for (uint32_t i = 0; i < n_obs; ++i) ++h->f_count[obs_feature[i]];
+    if (int rc = lay_out(h, true)) return rc;
+    return take_estimates();
+  }
+  // in place: one small kernel per kAppendMax readings carries the data as its arguments
+  h->f_count.resize(F1, 0);
+  h->f_cap.resize(F1, 32);
+  h->f_start.resize(size_t(F1) + 1);
+  for (uint32_t f = F0; f < F1; ++f) h->f_start[f] = new_start[f - F0];
+  h->f_start[F1] = end;
+  h->slots_used = end;
+  h->h_ot.resize(end, 0);
+  h->h_omu.resize(end, 0.0);
+  uint32_t done = 0, new_seen = 0;
+  do {
+    AppendArgs a{};
+    a.t = t;
+    a.has_control = ctrl_mean && done == 0;
+    if (a.has_control)
+      for (int k = 0; k < 3; ++k) {
+        a.cm[k] = ctrl_mean[k];
+        a.cs[k] = ctrl_stddev[k];
+      }
+    a.has_init_rel = a.has_control && take_irel;
+    if (a.has_init_rel)
+      for (int k = 0; k < 3; ++k) a.irel[k] = init_state_rel[k];
+    a.n = std::min<uint32_t>(kAppendMax, n_obs - done);
+    a.arrival0 = N0 + done;
+    a.arrivals_end = N0 + done + a.n;
+    for (uint32_t i = 0; i < a.n; ++i) {
+      const uint32_t j = done + i, f = obs_feature[j];
+      const uint32_t slot = h->f_start[f] + h->f_count[f];
+      a.slot[i] = slot;
+      a.f[i] = f;
+      a.is_new[i] = f >= F0;
+      a.mu[i] = obs_mean[j];
+      a.sd[i] = obs_stddev[j];
+      a.bmu[i] = rb ? bearing_mean[j] : 0.0;
+      a.bsd[i] = rb ? bearing_stddev[j] : 1.0;
+      if (a.is_new[i]) {
+        a.has_ifeat[i] = take_ifeat;
+        if (take_ifeat) {
+          a.ifeat[i][0] = init_feat_rel[2 * size_t(new_seen)];
+          a.ifeat[i][1] = init_feat_rel[2 * size_t(new_seen) + 1];
+        }
+        ++new_seen;
+      }
+      ++h->f_count[f];
+      h->h_ot[slot] = t;
+      h->h_omu[slot] = obs_mean[j];
+      h->h_tobs.push_back(slot);
+      if (N0 + j == 0)
+        h->sigma_all = obs_stddev[j], h->bsigma_all = rb ? bearing_stddev[j] : 0.0;
+      if (obs_stddev[j] != h->sigma_all) h->sigma_all = 0.0;
+      if (rb && bearing_stddev[j] != h->bsigma_all) h->bsigma_all = 0.0;
+    }
+    hipLaunchKernelGGL(append_kernel, dim3(1), dim3(64), 0, h->stream, d, a);
+    HIP_TRY(h, hipGetLastError());
+    done += a.n;
+  } while (done < n_obs);
+  if (take_irel) d.n_init_rel = T0 + 1;
+  if (take_ifeat && F1 > F0) d.n_init_feat = F1;
+  d.T = uint32_t(h->a_cmean.size() / 3);
+  d.N = uint32_t(h->a_t.size());
+  d.F = F1;
+  d.usig_inv = h->sigma_all > 0 ? 1.0 / h->sigma_all : 0.0;
+  d.ubsig_inv = h->bsigma_all > 0 ? 1.0 / h->bsigma_all : 0.0;
   h->problem_loaded = true;
   return 0;
 }
@@ -425,23 +652,27 @@ int mcmcgpu_set_bearings(mcmcgpu_handle h, uint32_t N, const double* bearing_mea
   if (!h->problem_loaded || N != h->d.N)
     return fail(h, MCMCGPU_ERR_ARGUMENT, "one bearing per reading of the uploaded problem is required");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
-  std::vector<double> mu(N), sd(N), isd(N);
+  for (uint32_t i = 0; i < N; ++i)
+    if (!(bearing_stddev[i] > 0)) return fail(h, MCMCGPU_ERR_ARGUMENT, "non-positive bearing stddev");
+  h->a_bmean.assign(bearing_mean, bearing_mean + N);
+  h->a_bsd.assign(bearing_stddev, bearing_stddev + N);
+  std::vector<double> mu(h->slots_used, 0.0), sd(h->slots_used, 1.0), isd(h->slots_used, 1.0);
   bool uniform_sigma = N > 0;
   for (uint32_t i = 0; i < N; ++i) {
-    if (!(bearing_stddev[i] > 0)) return fail(h, MCMCGPU_ERR_ARGUMENT, "non-positive bearing stddev");
     uniform_sigma = uniform_sigma && bearing_stddev[i] == bearing_stddev[0];
     const uint32_t pos = h->h_tobs[i];
     mu[pos] = bearing_mean[i];
     sd[pos] = bearing_stddev[i];
     isd[pos] = 1.0 / bearing_stddev[i];
   }
-  const size_t bytes = size_t(N) * sizeof(double);
-  if (N) {
+  const size_t bytes = size_t(h->slots_used) * sizeof(double);
+  if (bytes) {
     HIP_TRY(h, hipMemcpyAsync(const_cast<double*>(h->d.obear), mu.data(), bytes, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(const_cast<double*>(h->d.obsd), sd.data(), bytes, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(const_cast<double*>(h->d.obisd), isd.data(), bytes, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
   }
+  h->bsigma_all = uniform_sigma ? bearing_stddev[0] : 0.0;
   h->d.ubsig_inv = uniform_sigma ? 1.0 / bearing_stddev[0] : 0.0;
   h->bearings_loaded = true;
   return 0;
@@ -1023,7 +1254,7 @@ int mcmcgpu_load_state(mcmcgpu_handle h, uint32_t first, uint32_t count, const d
   // growth would end with (strictly smaller |range| wins, in time order)
   std::vector<uint32_t> fmeta(4 * size_t(F));
   for (uint32_t f = 0; f < F; ++f) {
-    const uint32_t lo = h->h_foff[f], hi = h->h_foff[f + 1];
+    const uint32_t lo = h->f_start[f], hi = lo + h->f_count[f];
     uint32_t par = lo;
     for (uint32_t o = lo + 1; o < hi; ++o)
       if (std::fabs(h->h_omu[o]) < std::fabs(h->h_omu[par])) par = o;

@@ -67,6 +67,10 @@ class device_problem {
   std::vector<std::uint32_t> ot, of;
   std::map<std::size_t, std::uint32_t> dense;
   std::vector<std::size_t> ids;  // dense index -> landmark id
+  // what append_to has handed over so far
+  bool sent_any = false;
+  std::uint32_t sent_T = 0, sent_F = 0;
+  std::size_t sent_N = 0;
 
  public:
   // range_bearing_model readings carry a second component (range_bearing_model.hpp:21-40)
@@ -107,6 +111,33 @@ class device_problem {
       }
     }
     return fresh;
+  }
+  // Online growth: hands the device every timestep absorbed since the last call, one
+  // mcmcgpu_append_timestep each (the whole problem is never uploaded again).  irel / ifeat: the
+  // initialiser's estimates per state edge (3 doubles) and per landmark (2 doubles, dense order),
+  // as far as they reach.
+  void append_to(mcmcgpu_handle h, const std::vector<double>* irel, const std::vector<double>* ifeat) {
+    while (!sent_any || sent_T < T()) {
+      const std::uint32_t tt = sent_any ? sent_T + 1 : 0;
+      std::size_t lo = sent_N, hi = lo;
+      while (hi < ot.size() && ot[hi] == tt) ++hi;
+      std::uint32_t fresh = 0;
+      for (std::size_t i = lo; i < hi; ++i)
+        if (of[i] >= sent_F + fresh) ++fresh;
+      const double* edge_estimate = irel && tt && irel->size() >= 3 * std::size_t(tt) ? irel->data() + 3 * std::size_t(tt - 1) : nullptr;
+      const double* landmark_estimates =
+          ifeat && fresh && ifeat->size() >= 2 * std::size_t(sent_F + fresh) ? ifeat->data() + 2 * std::size_t(sent_F) : nullptr;
+      check(h,
+            mcmcgpu_append_timestep(h, tt ? cmean.data() + 3 * std::size_t(tt - 1) : nullptr,
+                                    tt ? cstd.data() + 3 * std::size_t(tt - 1) : nullptr, std::uint32_t(hi - lo), of.data() + lo,
+                                    omean.data() + lo, ostd.data() + lo, bearing ? bmean.data() + lo : nullptr,
+                                    bearing ? bstd.data() + lo : nullptr, edge_estimate, landmark_estimates),
+            "mcmcgpu_append_timestep");
+      sent_any = true;
+      sent_T = tt;
+      sent_N = hi;
+      sent_F += fresh;
+    }
   }
   void upload(mcmcgpu_handle h) const {
     check(h, mcmcgpu_upload_problem(h, T(), cmean.data(), cstd.data(), N(), ot.data(), of.data(), omean.data(),
@@ -212,12 +243,8 @@ class mcmc_slam : public slam_result_of<ControlModel, ObservationModel> {
             -initialiser->get_state(timestep_type(f.second)) + initialiser->get_feature(featureid_type(problem.feature_ids()[f.first]));
         init_feat.insert(init_feat.end(), {p.x(), p.y()});
       }
-      detail::check(h,
-                    mcmcgpu_set_initial_estimates(h, std::uint32_t(init_rel.size() / 3), init_rel.data(),
-                                                  std::uint32_t(init_feat.size() / 2), init_feat.data()),
-                    "mcmcgpu_set_initial_estimates");
     }
-    problem.upload(h);
+    problem.append_to(h, initialiser ? &init_rel : nullptr, initialiser ? &init_feat : nullptr);
     detail::check(h, mcmcgpu_grow(h, std::uint32_t(std::size_t(t))), "mcmcgpu_grow");
     next_timestep = std::size_t(t) + 1;
     invalidate();
@@ -293,7 +320,7 @@ class mcmc_slam : public slam_result_of<ControlModel, ObservationModel> {
         : instance(instance), steps(steps), end_steps(end_steps) {}
     void timestep(timestep_type t) override {
       instance->timestep(t);
-      instance->update(steps);
+      instance->update_async(steps);  // queued behind the growth; nothing waits per timestep
     }
     void completed() override {
       instance->completed();

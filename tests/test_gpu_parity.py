@@ -776,3 +776,90 @@ def test_random_small_problems_match_oracle(case):
         assert np.array_equal(sg["feat_parent"], so["feat_parent"])
         assert_close(sg["cum"], so["cum"], REL, "cumulative poses")
         assert_close(sg["feat_est"], so["feat_est"], REL, "landmark estimates")
+
+
+def _append_all(g, p, upto_from=0, bearings=False, per_ts=3, end_steps=50, init_rel=None, init_feat=None):
+    """Feeds problem `p` to handle `g` one timestep at a time with mcmcgpu_append_timestep, advancing after each."""
+    seen = 0
+    for t in range(upto_from, p["T"] + 1):
+        lo = int(np.searchsorted(p["obs_t"], t, side="left"))
+        hi = int(np.searchsorted(p["obs_t"], t, side="right"))
+        f = p["obs_f"][lo:hi]
+        new = [int(x) for x in f if int(x) >= seen]
+        kw = {}
+        if bearings:
+            kw.update(bearing_mean=p["obs_bearing"][lo:hi], bearing_std=p["obs_bearing_std"][lo:hi])
+        if init_rel is not None and t > 0:
+            kw.update(init_state_rel=init_rel[t - 1])
+        if init_feat is not None and new:
+            kw.update(init_feat_rel=np.concatenate([init_feat[x] for x in new]))
+        g.append_timestep(None if t == 0 else p["ctrl_mean"][t - 1], None if t == 0 else p["ctrl_std"][t - 1], f,
+                          p["obs_mean"][lo:hi], p["obs_std"][lo:hi], **kw)
+        seen += len(new)
+        g.advance(t, steps_per_timestep=per_ts, end_steps=end_steps if t == p["T"] else 0)
+
+
+def test_appended_timesteps_equal_one_upload():
+    """mcmcgpu_append_timestep, timestep by timestep from an empty handle (in-place appends and the
+    re-layouts that make room), gives the chain of one upload followed by one online replay."""
+    p = small_problem(T=200, F=9, k=3, seed=5)
+    seeds = np.array([77, 78], dtype=np.uint32)
+    g1 = gpu_handle(p, seeds, trace_capacity=2048)
+    g1.advance(p["T"], steps_per_timestep=3, end_steps=50)
+    g1.sync()
+    g2 = capi.McmcGpu(2, p["T"], p["F"], p["N"], trace_capacity=2048)
+    g2.init_chains(seeds)
+    _append_all(g2, p)
+    g2.sync()
+    for c in range(2):
+        t1, t2 = g1.trace(c), g2.trace(c)
+        assert len(t1) == len(t2)
+        for name in ("kind", "index", "accepted", "log_ratio", "log_likelihood", "proposed"):
+            assert np.array_equal(t1[name], t2[name]), name
+    assert np.array_equal(g1.full_log_likelihood(), g2.full_log_likelihood())
+    # ... and continuing an uploaded problem by appends (compact layout first, then room to grow)
+    half = 100
+    n = int(np.searchsorted(p["obs_t"], half, side="right"))
+    F = int(p["obs_f"][:n].max()) + 1
+    g3 = capi.McmcGpu(2, p["T"] + 4, p["F"], p["N"] + 8, trace_capacity=2048)
+    g3.upload_problem(p["ctrl_mean"][:half], p["ctrl_std"][:half], p["obs_t"][:n], p["obs_f"][:n], p["obs_mean"][:n],
+                      p["obs_std"][:n], F)
+    g3.init_chains(seeds)
+    g3.advance(half, steps_per_timestep=3, end_steps=0)
+    q = dict(p)
+    _append_all(g3, q, upto_from=half + 1)
+    g3.sync()
+    # same chain as g1 only up to the hand-over (g1's replay interleaves identically): compare end state
+    for c in range(2):
+        t1, t3 = g1.trace(c), g3.trace(c)
+        assert len(t1) == len(t3)
+        assert np.array_equal(t1["accepted"], t3["accepted"]) and np.array_equal(t1["log_likelihood"], t3["log_likelihood"])
+    with pytest.raises(RuntimeError, match="dense"):
+        g3.append_timestep(p["ctrl_mean"][0], p["ctrl_std"][0], [p["F"] + 5], [1.0], [1.0])
+    with pytest.raises(RuntimeError, match="two readings"):
+        g3.append_timestep(p["ctrl_mean"][0], p["ctrl_std"][0], [0, 0], [1.0, 1.0], [1.0, 1.0])
+
+
+def test_appended_timesteps_with_bearings_and_initial_estimates():
+    """The same for range-and-bearing readings, with an initialiser's estimates handed over edge by edge."""
+    p = _rb_problem(T=150, F=8, k=3, seed=13)
+    seeds = np.array([31], dtype=np.uint32)
+    rng = np.random.default_rng(4)
+    init_rel = p["true_rel"] + rng.normal(0, [0.01, 0.01, 0.002], size=p["true_rel"].shape)
+    init_feat = rng.normal(0, 3.0, size=(p["F"], 2))
+    g1 = capi.McmcGpu(1, p["T"], p["F"], p["N"], trace_capacity=2048, range_bearing=True)
+    g1.upload_problem(p["ctrl_mean"], p["ctrl_std"], p["obs_t"], p["obs_f"], p["obs_mean"], p["obs_std"], p["F"])
+    g1.set_bearings(p["obs_bearing"], p["obs_bearing_std"])
+    g1.init_chains(seeds)
+    g1.set_initial_estimates(init_rel, init_feat)
+    g1.advance(p["T"], steps_per_timestep=2, end_steps=40)
+    g1.sync()
+    g2 = capi.McmcGpu(1, p["T"], p["F"], p["N"], trace_capacity=2048, range_bearing=True)
+    g2.init_chains(seeds)
+    _append_all(g2, p, bearings=True, per_ts=2, end_steps=40, init_rel=init_rel, init_feat=init_feat)
+    g2.sync()
+    t1, t2 = g1.trace(0), g2.trace(0)
+    assert len(t1) == len(t2)
+    for name in ("kind", "index", "accepted", "log_ratio", "log_likelihood", "proposed"):
+        assert np.array_equal(t1[name], t2[name]), name
+    assert np.array_equal(g1.get_state(0)["cum"], g2.get_state(0)["cum"])
