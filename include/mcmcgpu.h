@@ -59,6 +59,11 @@ typedef struct mcmcgpu_config {
    * stream may be cut into; 0 = no split mode, and no memory set aside for it
    * (44 bytes per chain and landmark). */
   uint32_t max_split_slices;
+  /* Split mode: from this many poses on, the pose-table update of an accepted
+   * state edge runs as a kernel of its own with many workgroups per chain
+   * instead of inside the chain's own workgroup; 0 = the default (200 000). */
+  uint32_t split_commit_min_poses;
+  uint32_t reserved; /* 0 */
 } mcmcgpu_config;
 
 /* One Metropolis-Hastings step as recorded when trace_capacity > 0. */

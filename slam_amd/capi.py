@@ -27,6 +27,8 @@ class Config(ctypes.Structure):
         ("stream", ctypes.c_void_p),
         ("range_bearing", ctypes.c_uint32),
         ("max_split_slices", ctypes.c_uint32),
+        ("split_commit_min_poses", ctypes.c_uint32),
+        ("reserved", ctypes.c_uint32),
     ]
 
 
@@ -158,10 +160,11 @@ class McmcGpu:
 
     def __init__(self, max_chains, max_timesteps, max_features, max_observations, device=0,
                  threads_per_chain=0, feature_uniform_first=True, trace_capacity=0, stream=None, range_bearing=False,
-                 max_split_slices=0):
+                 max_split_slices=0, split_commit_min_poses=0):
         self.lib = load_library()
         cfg = Config(device, max_chains, max_timesteps, max_features, max_observations, threads_per_chain,
-                     1 if feature_uniform_first else 0, trace_capacity, stream, 1 if range_bearing else 0, max_split_slices)
+                     1 if feature_uniform_first else 0, trace_capacity, stream, 1 if range_bearing else 0, max_split_slices,
+                     split_commit_min_poses, 0)
         self.h = ctypes.c_void_p()
         rc = self.lib.mcmcgpu_create(ctypes.byref(cfg), ctypes.byref(self.h))
         if rc != 0:

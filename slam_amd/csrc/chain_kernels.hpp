@@ -112,6 +112,10 @@ struct ChainCtl {
   double Ws, Wf, new_pll, old_pll, q[3];
   int32_t w_dirty, op, pending, use_weight;
   uint32_t idx, total;
+  // an accepted state edge whose pose-table update is left to split_commit_kernel: poses from
+  // move_from on turn by (move_sin, move_cos) about move_pivot and land at move_to; angle + move_dth
+  uint32_t move_from;  // 0 = nothing to move
+  double move_pivot[2], move_to[2], move_sin, move_cos, move_dth;
 };
 
 constexpr int kMaxSeg = 256;   // landmark segments evaluated per pass
@@ -119,6 +123,16 @@ constexpr int kActCap = 1024;  // landmarks examined per round (blockDim.x divid
 constexpr int kMaxWaves = 16;
 constexpr int kTileShift = 8;  // poses per tile of the rebuild scan = 256
 constexpr uint32_t kMaxRetry = 1u << 16;
+
+// Slices a chain's stream of `total` readings is cut into in split mode: as many as the launch
+// offers, but no slice shorter than kSplitMinChunk readings -- a small proposal (one landmark's
+// list) occupies a few workgroups, a large one all of them.  It depends on the chain's own
+// proposal only, so a chain's arithmetic does not depend on which other chains share the launch.
+constexpr uint32_t kSplitMinChunk = 1024;
+__device__ __forceinline__ uint32_t active_slices(uint32_t total, uint32_t offered) {
+  const uint32_t n = (total + kSplitMinChunk - 1) / kSplitMinChunk;
+  return n < 1 ? 1 : (n > offered ? offered : n);
+}
 
 enum Op : int { OP_END = 0, OP_EVAL_STATE = 1, OP_EVAL_FEATURE = 2 };
 enum Pending : int { PEND_NONE = 0, PEND_UPDATE = 1, PEND_REPARENT = 2 };
@@ -799,21 +813,32 @@ MG_DEV double eval_state_edge(const Dev& d, uint32_t c, Shared& S, uint32_t t, c
 // D = P[t] o q o P[t+1]^-1, applied as a rotation about the old P[t+1] so no
 // large coordinates cancel: P'[k].t = A.t + R(D.th) (P[k].t - P[t+1].t) with
 // A = P[t] o q the new pose t+1.
-MG_DEV void commit_state_edge(const Dev& d, uint32_t c, uint32_t t, const Pose& q, uint32_t Tcur) {
-  const uint32_t k1 = t + 1;
-  const size_t base = size_t(c) * (d.Tcap + 1);
-  const Pose Pt = world_pose(d, c, t), Pt1 = world_pose(d, c, k1);
+struct PoseMove {
+  double pivot_x, pivot_y, to_x, to_y, s, c, dth;
+};
+MG_DEV PoseMove pose_move_of(const Dev& d, uint32_t c, uint32_t t, const Pose& q) {
+  const Pose Pt = world_pose(d, c, t), Pt1 = world_pose(d, c, t + 1);
   const Pose A = compose(Pt, q);
-  const double Dth = q.th - d.relth[size_t(c) * d.Tcap + t];
-  double sD, cD;
-  sincos(Dth, &sD, &cD);
+  PoseMove m;
+  m.dth = q.th - d.relth[size_t(c) * d.Tcap + t];
+  sincos(m.dth, &m.s, &m.c);
+  m.pivot_x = Pt1.x;
+  m.pivot_y = Pt1.y;
+  m.to_x = A.x;
+  m.to_y = A.y;
+  return m;
+}
+MG_DEV void move_pose(const Dev& d, size_t i, const PoseMove& m) {
+  const PoseXY p = d.pxy[i];
+  const double dx = p.x - m.pivot_x, dy = p.y - m.pivot_y;
+  d.pxy[i] = PoseXY{m.to_x + (m.c * dx - m.s * dy), m.to_y + (m.s * dx + m.c * dy)};
+  d.pth[i] += m.dth;
+}
+MG_DEV void commit_state_edge(const Dev& d, uint32_t c, uint32_t t, const Pose& q, uint32_t Tcur) {
+  const size_t base = size_t(c) * (d.Tcap + 1);
+  const PoseMove m = pose_move_of(d, c, t, q);
   __syncthreads();  // every lane holds the old pivot before anything is overwritten
-  for (uint32_t k = k1 + threadIdx.x; k <= Tcur; k += blockDim.x) {
-    const PoseXY p = d.pxy[base + k];
-    const double dx = p.x - Pt1.x, dy = p.y - Pt1.y;
-    d.pxy[base + k] = PoseXY{A.x + (cD * dx - sD * dy), A.y + (sD * dx + cD * dy)};
-    d.pth[base + k] += Dth;
-  }
+  for (uint32_t k = t + 1 + threadIdx.x; k <= Tcur; k += blockDim.x) move_pose(d, base + k, m);
 }
 
 // ---------------------------------------------------------------------------
@@ -1366,13 +1391,15 @@ MG_DEV void shared_to_ctl(const Dev& d, uint32_t c, const Shared& S) {
 __global__ void __launch_bounds__(256) split_eval_rb_kernel(Dev d_by_value) {
   MG_KERNEL_DEV(d);
   __shared__ double red[4];
-  const uint32_t c = blockIdx.y, slices = gridDim.x, nf = d.nf[c];
+  const uint32_t c = blockIdx.y, nf = d.nf[c];
   const uint32_t* __restrict__ segpre = d.sp_segpre + size_t(c) * (d.Fcap + 1);
   const uint32_t* __restrict__ seglo = d.sp_seglo + size_t(c) * d.Fcap;
   const double* __restrict__ w4 = d.sp_segw + 4 * size_t(c) * d.Fcap;
   const PoseXY* __restrict__ poses = d.pxy + size_t(c) * (d.Tcap + 1);
   const double* __restrict__ pth = d.pth + size_t(c) * (d.Tcap + 1);
   const uint32_t total = nf ? segpre[nf] : 0;
+  const uint32_t slices = active_slices(total, gridDim.x);
+  if (blockIdx.x >= slices) return;
   const uint32_t per = (total + slices - 1) / slices;
   const uint32_t lo = min(total, blockIdx.x * per), hi = min(total, lo + per);
   const bool usig = d.usig_inv > 0.0 && d.ubsig_inv > 0.0;
@@ -1429,7 +1456,8 @@ __global__ void __launch_bounds__(256) split_eval_rb_kernel(Dev d_by_value) {
 // update k + 1 -- selection and proposal (:339-382) -- in one kernel, so that the chain's generator
 // and scalars are fetched once for both.  finish = 0 on the first call of a run (nothing to end;
 // the weight totals are computed afresh), begin = 0 on the last.
-__global__ void split_ends_kernel(Dev d_by_value, uint32_t Tcur, uint32_t slices, uint32_t finish, uint32_t begin) {
+__global__ void split_ends_kernel(Dev d_by_value, uint32_t Tcur, uint32_t slices, uint32_t finish, uint32_t begin,
+                                  uint32_t defer_commit) {
   MG_KERNEL_DEV(d);
   __shared__ Shared S;
   const uint32_t c = blockIdx.x;
@@ -1443,7 +1471,8 @@ __global__ void split_ends_kernel(Dev d_by_value, uint32_t Tcur, uint32_t slices
       S.n_upd = 1;
       if (S.op != OP_END) {
         double r = 0.0;
-        for (uint32_t k = 0; k < slices; ++k) r += d.sp_partial[size_t(c) * d.max_slices + k];
+        const uint32_t used = active_slices(d.ctl[c].total, slices);
+        for (uint32_t k = 0; k < used; ++k) r += d.sp_partial[size_t(c) * d.max_slices + k];
         S.n_units = d.ctl[c].total;
         if (S.op == OP_EVAL_STATE) S.n_state = 1;
         const bool accept = driver_finish_update(d, c, S, r);
@@ -1454,9 +1483,26 @@ __global__ void split_ends_kernel(Dev d_by_value, uint32_t Tcur, uint32_t slices
     }
   }
   __syncthreads();
+  if (threadIdx.x == 0) d.ctl[c].move_from = 0;
   if (S.op == OP_EVAL_STATE && S.accept) {
     const Pose q{S.q[0], S.q[1], S.q[2]};
-    commit_state_edge(d, c, S.idx, q, Tcur);
+    if (defer_commit) {  // split_commit_kernel moves the poses, with many workgroups
+      if (threadIdx.x == 0) {
+        const PoseMove m = pose_move_of(d, c, S.idx, q);
+        ChainCtl& k = d.ctl[c];
+        k.move_from = S.idx + 1;
+        k.move_pivot[0] = m.pivot_x;
+        k.move_pivot[1] = m.pivot_y;
+        k.move_to[0] = m.to_x;
+        k.move_to[1] = m.to_y;
+        k.move_sin = m.s;
+        k.move_cos = m.c;
+        k.move_dth = m.dth;
+      }
+    } else {
+      commit_state_edge(d, c, S.idx, q, Tcur);
+    }
+    __syncthreads();  // the old relative angle has been read
     if (threadIdx.x == 0) {
       const size_t ri = size_t(c) * d.Tcap + S.idx;
       d.relx[ri] = q.x;
@@ -1472,6 +1518,22 @@ __global__ void split_ends_kernel(Dev d_by_value, uint32_t Tcur, uint32_t slices
     shared_to_ctl(d, c, S);
   }
   chain_state_store(d, c, S);
+}
+
+// The pose table of the chains whose state-edge proposal split_ends_kernel has just accepted
+// (ChainCtl::move_from != 0); grid = (pieces, chains).  A million poses are one workgroup's work for
+// milliseconds, which the other chains of the launch would wait for.
+__global__ void split_commit_kernel(Dev d_by_value, uint32_t Tcur) {
+  MG_KERNEL_DEV(d);
+  const uint32_t c = blockIdx.y;
+  const ChainCtl& k = d.ctl[c];
+  const uint32_t from = k.move_from;
+  if (from == 0 || from > Tcur) return;
+  const PoseMove m{k.move_pivot[0], k.move_pivot[1], k.move_to[0], k.move_to[1], k.move_sin, k.move_cos, k.move_dth};
+  const size_t base = size_t(c) * (d.Tcap + 1);
+  const uint32_t n = Tcur - from + 1, per = (n + gridDim.x - 1) / gridDim.x;
+  const uint32_t lo = from + blockIdx.x * per, hi = min(Tcur + 1, lo + per);
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) move_pose(d, base + i, m);
 }
 
 // One lane per landmark: its affected readings and its old and moved position (phases A and B
@@ -1539,16 +1601,21 @@ __global__ void split_scan_kernel(Dev d_by_value) {
   }
 }
 
-// The reading stream of one proposal, slice blockIdx.x of gridDim.x of chain blockIdx.y.
+// The reading stream of one proposal, slice blockIdx.x of chain blockIdx.y (see active_slices).
+// Two readings per lane per group; the records of the next group are requested before the
+// current group is evaluated, so that their latency hides behind its arithmetic.
 __global__ void __launch_bounds__(256) split_eval_kernel(Dev d_by_value) {
   MG_KERNEL_DEV(d);
   __shared__ double red[4];
-  const uint32_t c = blockIdx.y, slices = gridDim.x, nf = d.nf[c];
+  const uint32_t c = blockIdx.y, nf = d.nf[c];
   const uint32_t* __restrict__ segpre = d.sp_segpre + size_t(c) * (d.Fcap + 1);
   const uint32_t* __restrict__ seglo = d.sp_seglo + size_t(c) * d.Fcap;
   const double* __restrict__ w4 = d.sp_segw + 4 * size_t(c) * d.Fcap;
   const PoseXY* __restrict__ poses = d.pxy + size_t(c) * (d.Tcap + 1);
+  const ObsRec* __restrict__ orec = d.orec;
   const uint32_t total = nf ? segpre[nf] : 0;
+  const uint32_t slices = active_slices(total, gridDim.x);
+  if (blockIdx.x >= slices) return;
   const uint32_t per = (total + slices - 1) / slices;
   const uint32_t lo = min(total, blockIdx.x * per), hi = min(total, lo + per);
   double acc = 0.0;
@@ -1571,8 +1638,9 @@ __global__ void __launch_bounds__(256) split_eval_kernel(Dev d_by_value) {
     const double half_isd2 = 0.5 * d.usig_inv * d.usig_inv;
     constexpr int U = 2;
     constexpr uint32_t stride = 256;
-    for (uint32_t i0 = lo + threadIdx.x; i0 < hi; i0 += U * stride) {
-      uint32_t o[U], sg[U];
+    ObsRec rec[U];
+    uint32_t o[U], sg[U];
+    auto fetch = [&](uint32_t i0) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const uint32_t i = i0 + u * stride;
@@ -1588,23 +1656,32 @@ __global__ void __launch_bounds__(256) split_eval_kernel(Dev d_by_value) {
         }
         sg[u] = cur;
       }
-      ObsRec rec[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) rec[u] = d.orec[o[u]];
+      for (int u = 0; u < U; ++u) rec[u] = orec[o[u]];
+    };
+    fetch(lo + threadIdx.x);
+    for (uint32_t i0 = lo + threadIdx.x; i0 < hi; i0 += U * stride) {
       PoseXY p[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) p[u] = poses[rec[u].t];
+      double mu[U], k[U];
+      uint32_t s_[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const double* w = w4 + 4 * size_t(sg[u]);
-        const double ro = range_of(w[0] - p[u].x, w[1] - p[u].y);
-        const double rn = range_of(w[2] - p[u].x, w[3] - p[u].y);
-        double k = half_isd2;
+        p[u] = poses[rec[u].t];
+        mu[u] = rec[u].mu;
+        s_[u] = sg[u];
+        k[u] = half_isd2;
         if (!usig) {
           const double isd = d.oisd[o[u]];
-          k = 0.5 * isd * isd;
+          k[u] = 0.5 * isd * isd;
         }
-        const double term = (ro - rn) * fma(-2.0, rec[u].mu, ro + rn) * k;
+      }
+      if (i0 + U * stride < hi) fetch(i0 + U * stride);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const double* w = w4 + 4 * size_t(s_[u]);
+        const double ro = range_of(w[0] - p[u].x, w[1] - p[u].y);
+        const double rn = range_of(w[2] - p[u].x, w[3] - p[u].y);
+        const double term = (ro - rn) * fma(-2.0, mu[u], ro + rn) * k[u];
         if (i0 + u * stride < hi) acc += term;
       }
     }

@@ -110,6 +110,7 @@ int dev_alloc(mcmcgpu_handle h, T** out, size_t count) {
 
 uint32_t edges_grown(const mcmcgpu_ctx* h) { return h->next_timestep == 0 ? 0 : h->next_timestep - 1; }
 
+constexpr uint32_t kDeferCommitPoses = 200000;  // split mode: trajectories from here on get split_commit_kernel
 constexpr uint32_t kMaxOwnReports = 256;  // intervals of one launch the library can hold itself
 
 bool is_pow2(uint32_t v) { return v && !(v & (v - 1)); }
@@ -849,8 +850,13 @@ int mcmcgpu_run_split(mcmcgpu_handle h, uint32_t steps, uint32_t slices) {
   EventPair ev;  // the whole sequence counts as one timed launch (mcmcgpu_kernel_time)
   if (int rc = begin_timed(h, &ev)) return rc;
   hipError_t launch_error = hipSuccess;
-  // ends(begin 1) | setup, scan, eval, ends(finish k, begin k+1) | ... : 1 + 4 * steps launches
-  if (steps) hipLaunchKernelGGL(split_ends_kernel, dim3(C), dim3(256), 0, h->stream, h->d, T, slices, 0u, 1u);
+  // ends(begin 1) | setup, scan, eval, ends(finish k, begin k+1) [, commit] | ... : 1 + 4 (5) * steps launches
+  // an accepted state edge moves every later pose: on a long trajectory that is a kernel of its own
+  // with many workgroups per chain, on a short one the ends kernel does it on the way
+  const uint32_t defer_from = h->cfg.split_commit_min_poses ? h->cfg.split_commit_min_poses : kDeferCommitPoses;
+  const uint32_t defer = T >= defer_from ? 1u : 0u;
+  const uint32_t pieces = std::max<uint32_t>(1, std::min<uint32_t>(64, (T + 4095) / 4096));
+  if (steps) hipLaunchKernelGGL(split_ends_kernel, dim3(C), dim3(256), 0, h->stream, h->d, T, slices, 0u, 1u, defer);
   for (uint32_t i = 0; i < steps; ++i) {
     hipLaunchKernelGGL(split_setup_kernel, dim3(fblocks, C), dim3(256), 0, h->stream, h->d, T);
     hipLaunchKernelGGL(split_scan_kernel, dim3(C), dim3(256), 0, h->stream, h->d);
@@ -858,7 +864,9 @@ int mcmcgpu_run_split(mcmcgpu_handle h, uint32_t steps, uint32_t slices) {
       hipLaunchKernelGGL(split_eval_rb_kernel, dim3(slices, C), dim3(256), 0, h->stream, h->d);
     else
       hipLaunchKernelGGL(split_eval_kernel, dim3(slices, C), dim3(256), 0, h->stream, h->d);
-    hipLaunchKernelGGL(split_ends_kernel, dim3(C), dim3(256), 0, h->stream, h->d, T, slices, 1u, i + 1 < steps ? 1u : 0u);
+    hipLaunchKernelGGL(split_ends_kernel, dim3(C), dim3(256), 0, h->stream, h->d, T, slices, 1u, i + 1 < steps ? 1u : 0u,
+                       defer);
+    if (defer) hipLaunchKernelGGL(split_commit_kernel, dim3(pieces, C), dim3(256), 0, h->stream, h->d, T);
     if ((launch_error = hipGetLastError()) != hipSuccess) break;
   }
   return end_timed(h, ev, launch_error, "split-mode launch");

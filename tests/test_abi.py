@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_the_header():
     assert capi.STEP_RECORD.itemsize == 56
     assert capi.CHAIN_SUMMARY.itemsize == 16
-    assert ctypes.sizeof(capi.Config) == 48
+    assert ctypes.sizeof(capi.Config) == 56
 
 
 def test_host_seed_helpers_match_oracle():

@@ -863,3 +863,24 @@ def test_appended_timesteps_with_bearings_and_initial_estimates():
     for name in ("kind", "index", "accepted", "log_ratio", "log_likelihood", "proposed"):
         assert np.array_equal(t1[name], t2[name]), name
     assert np.array_equal(g1.get_state(0)["cum"], g2.get_state(0)["cum"])
+
+
+def test_split_mode_with_the_pose_update_as_a_kernel_of_its_own():
+    """Accepted state edges moved by split_commit_kernel (the path long trajectories take) give the
+    chain the ends kernel's own update gives, bit for bit."""
+    p = small_problem(T=500, F=14, k=4, seed=9, range_stddev=3.0)
+    seeds = capi.seed_sequence(555, 3)
+    steps = 400
+    out = []
+    for min_poses in (0, 1):  # 0: the default threshold (200 000 poses, not reached here); 1: always
+        g = gpu_handle(p, seeds, trace_capacity=4096, max_split_slices=8, split_commit_min_poses=min_poses)
+        g.grow(p["T"])
+        g.run_split(steps, 8)
+        g.sync()
+        out.append((g.trace(0), g.trace(2), g.log_likelihood(), g.full_log_likelihood(), g.get_state(1)["cum"]))
+    assert out[0][0]["accepted"].sum() > 5 and (out[0][0]["kind"][out[0][0]["accepted"] == 1] == 0).any()
+    for a, b in zip(out[0][:2], out[1][:2]):
+        for name in ("kind", "index", "accepted", "log_ratio", "log_likelihood", "proposed"):
+            assert np.array_equal(a[name], b[name]), name
+    for a, b in zip(out[0][2:], out[1][2:]):
+        assert np.array_equal(a, b)
