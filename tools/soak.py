@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Long run on the benchmark's problem with the invariants checked as it goes: after every launch the
 incremental log likelihood of every chain against the from-scratch one (1e-9 relative), no chain stopped,
-counters consistent.  tools/soak.py [launches=50] [updates per launch=1000] [rebuild every=5]"""
+counters consistent.  tools/soak.py [launches=50] [updates per launch=1000] [rebuild every=5] [chains=1024]
+[split slices=0: the persistent kernel; >0: split mode with that many slices]"""
 import os
 import sys
 import time
@@ -17,15 +18,19 @@ def main():
     per = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     rebuild_every = int(sys.argv[3]) if len(sys.argv) > 3 else 5
     p = synthetic.make_problem(T=100_000, n_landmarks=1000, k_nearest=10, seed=12345)
-    C = 1024
-    g = capi.McmcGpu(C, p["T"], p["F"], p["N"])
+    C = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
+    slices = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+    g = capi.McmcGpu(C, p["T"], p["F"], p["N"], max_split_slices=slices, split_commit_min_poses=1 if slices else 0)
     g.upload_problem(p["ctrl_mean"], p["ctrl_std"], p["obs_t"], p["obs_f"], p["obs_mean"], p["obs_std"], p["F"])
     g.init_chains(capi.seed_sequence(777, C))
     g.load_state(p["true_rel"], p["landmarks"])
     worst = 0.0
     t0 = time.perf_counter()
     for i in range(launches):
-        g.run(per)
+        if slices:
+            g.run_split(per, slices)
+        else:
+            g.run(per)
         if rebuild_every and (i + 1) % rebuild_every == 0:
             g.rebuild()
         g.sync()  # raises if a chain set its error flag
@@ -37,7 +42,8 @@ def main():
         print(f"launch {i + 1}: drift {rel.max():.2e} (worst {worst:.2e}), accepts per chain "
               f"{acc.mean():.1f}, best ll {ll.max():.3f}, {time.perf_counter() - t0:.0f} s", flush=True)
         assert rel.max() < 1e-9, "incremental log likelihood drifted from the from-scratch value"
-    print(f"soak ok: {launches * per} updates on each of {C} chains, worst drift {worst:.2e}")
+    mode = f"split mode, {slices} slices, pose updates by split_commit_kernel" if slices else "persistent kernel"
+    print(f"soak ok ({mode}): {launches * per} updates on each of {C} chains, worst drift {worst:.2e}")
 
 
 if __name__ == "__main__":
