@@ -287,7 +287,10 @@ MG_DEV double wrap_residual(double a) {
 // ---------------------------------------------------------------------------
 // The hot loop: sum over the prepared segments of
 //   ll(|w_new - t_s|) - ll(|w_old - t_s|)                      (mcmc_slam.hpp:487-502)
-// as a software pipeline.  A reading needs two dependent loads (its record,
+// With z = (r - mu)/sigma the term is -(zn^2 - zo^2)/2, evaluated as
+// (ro - rn) (ro + rn - 2 mu) / (2 sigma^2): the same number without cancelling two large squares.
+// Per reading: one 16-byte record, one 16-byte pose.  It runs as a software
+// pipeline.  A reading needs two dependent loads (its record,
 // then the pose of the record's timestep), each about 1.5 us away under load,
 // against ~1000 cycles of fp64 work per group of readings; with four
 // wavefronts per SIMD that latency is only hidden if both loads of LATER
@@ -393,8 +396,13 @@ struct RatioStream {
   }
 };
 
-// The same pipeline for range-AND-bearing readings (arithmetic: see eval_segments_rb): a record
-// brings its measured bearing along, a pose its angle.  USIG here means that the ranges and the
+// The same pipeline for range-AND-bearing readings (range_bearing_model,
+// src/planar_robot/range_bearing_model.hpp:21-117).  Seen from pose s the landmark is at
+// R(-th_s) (w - t_s): its range is |w - t_s| and its bearing atan2(w - t_s) - th_s, so a record
+// brings its measured bearing along and a pose its angle -- per reading 16 B record + 8 B bearing +
+// 16 B translation + 8 B angle = 48 bytes.  With z_r = (r - mu_r) / sigma_r and z_b =
+// wrap(b - mu_b) / sigma_b the term is -(z_r'^2 + z_b'^2) / 2 + (z_r^2 + z_b^2) / 2, each
+// difference of squares taken as a product so that nothing large cancels.  USIG here means that the ranges and the
 // bearings each have one sigma for all readings.  A struct of its own, so that the range-only
 // stream's code does not change with it (sharing one template cost the range-only stream 5 %).
 template <bool USIG>
@@ -531,23 +539,14 @@ MG_DEV double eval_ratio(const Dev& d, uint32_t c, const Shared& S, uint32_t nse
 }
 
 // ---------------------------------------------------------------------------
-// Generic (unpipelined) form of the same loop: all lanes stream the readings
-// of the prepared segments, gather the pose translation of each reading's
-// timestep and accumulate
-//   FULL == false:  ll(|w_new - t_s|) - ll(|w_old - t_s|)     (mcmc_slam.hpp:487-502)
-//   FULL == true :  ll(|w_old - t_s|) with its constants       (slam_likelihood.hpp:48-54)
-// With z = (r - mu)/sigma the ratio term is -(zn^2 - zo^2)/2, evaluated as
-// (ro - rn) (ro + rn - 2 mu) / (2 sigma^2): the same number without cancelling
-// two large squares.  Per reading: one 16-byte record, one 16-byte pose.
-template <bool FULL>
-MG_DEV double eval_segments(const Dev& d, uint32_t c, const Shared& S, uint32_t nseg) {
+// The from-scratch likelihood over prepared segments (slam_likelihood.hpp:48-54): all lanes stream
+// the readings, gather the pose translation of each reading's timestep and accumulate
+// ll(|w - t_s|) with its constants.  Plain four-deep loop; it runs once per read-out, not per proposal.
+MG_DEV double full_ll_segments(const Dev& d, uint32_t c, const Shared& S, uint32_t nseg) {
   const uint32_t total = S.segpre[nseg];
   const PoseXY* __restrict__ pxy = d.pxy + size_t(c) * (d.Tcap + 1);
   const ObsRec* __restrict__ orec = d.orec;
-  const double* __restrict__ oisd = d.oisd;
   const double* __restrict__ osd = d.osd;
-  const bool usig = d.usig_inv > 0.0;
-  const double half_isd2 = 0.5 * d.usig_inv * d.usig_inv;
   double acc = 0.0;
   uint32_t cur = 0;
   // kUnroll readings per lane are in flight at once to cover the latency of the
@@ -578,36 +577,19 @@ MG_DEV double eval_segments(const Dev& d, uint32_t c, const Shared& S, uint32_t 
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
       const double ro = range_of(S.segw[sg[u]][0] - p[u].x, S.segw[sg[u]][1] - p[u].y);
-      double term;
-      if (FULL) {
-        const double sd = osd[o[u]];
-        const double zo = (ro - rec[u].mu) / sd;
-        term = -0.5 * (zo * zo) - 0.5 * log(2 * kPi) - log(sd);
-      } else {
-        const double rn = range_of(S.segw[sg[u]][2] - p[u].x, S.segw[sg[u]][3] - p[u].y);
-        double k = half_isd2;
-        if (!usig) {
-          const double isd = oisd[o[u]];
-          k = 0.5 * isd * isd;
-        }
-        term = (ro - rn) * fma(-2.0, rec[u].mu, ro + rn) * k;
-      }
+      const double sd = osd[o[u]];
+      const double zo = (ro - rec[u].mu) / sd;
+      const double term = -0.5 * (zo * zo) - 0.5 * log(2 * kPi) - log(sd);
       if (ok[u]) acc += term;
     }
   }
   return acc;
 }
 
-// The same loops for range-AND-bearing readings (range_bearing_model,
-// src/planar_robot/range_bearing_model.hpp:21-117).  Seen from pose s the landmark is at
-// R(-th_s) (w - t_s): its range is |w - t_s| and its bearing atan2(w - t_s) - th_s, so a reading
-// needs the pose's angle too -- per reading 16 B record + 8 B measured bearing + 16 B translation
-// + 8 B angle = 48 bytes.  Residuals: z_r = (r - mu_r) / sigma_r, z_b = wrap(b - mu_b) / sigma_b;
-//   FULL == false:  -(z_r'^2 + z_b'^2) / 2 + (z_r^2 + z_b^2) / 2, each difference of squares as a
-//                   product so that nothing large cancels;
-//   FULL == true :  the log density itself (src/utility/random.hpp:116-121, two dimensions).
-template <bool FULL>
-MG_DEV double eval_segments_rb(const Dev& d, uint32_t c, const Shared& S, uint32_t nseg) {
+// The same for range-AND-bearing readings (range_bearing_model,
+// src/planar_robot/range_bearing_model.hpp:21-117): the log density of src/utility/random.hpp:116-121
+// in two dimensions, residuals z_r = (r - mu_r) / sigma_r, z_b = wrap(b - mu_b) / sigma_b.
+MG_DEV double full_ll_segments_rb(const Dev& d, uint32_t c, const Shared& S, uint32_t nseg) {
   const uint32_t total = S.segpre[nseg];
   const PoseXY* __restrict__ pxy = d.pxy + size_t(c) * (d.Tcap + 1);
   const double* __restrict__ pth = d.pth + size_t(c) * (d.Tcap + 1);
@@ -653,17 +635,8 @@ MG_DEV double eval_segments_rb(const Dev& d, uint32_t c, const Shared& S, uint32
       const double ox = w[0] - p[u].x, oy = w[1] - p[u].y;
       const double ro = range_of(ox, oy);
       const double eo = wrap_residual(atan2(oy, ox) - th[u] - bm[u]);
-      double term;
-      if (FULL) {
-        const double zr = (ro - rec[u].mu) * isd, zb = eo * ibsd;
-        term = -0.5 * (zr * zr + zb * zb) - log(2 * kPi) - (log(d.osd[o[u]]) + log(d.obsd[o[u]]));
-      } else {
-        const double nx = w[2] - p[u].x, ny = w[3] - p[u].y;
-        const double rn = range_of(nx, ny);
-        const double en = wrap_residual(atan2(ny, nx) - th[u] - bm[u]);
-        term = (ro - rn) * fma(-2.0, rec[u].mu, ro + rn) * (0.5 * isd * isd) +
-               (eo - en) * (eo + en) * (0.5 * ibsd * ibsd);
-      }
+      const double zr = (ro - rec[u].mu) * isd, zb = eo * ibsd;
+      const double term = -0.5 * (zr * zr + zb * zb) - log(2 * kPi) - (log(d.osd[o[u]]) + log(d.obsd[o[u]]));
       if (ok[u]) acc += term;
     }
   }
@@ -1387,7 +1360,7 @@ MG_DEV void shared_to_ctl(const Dev& d, uint32_t c, const Shared& S) {
 }
 
 // The reading stream of one proposal for range-and-bearing readings (the arithmetic of
-// eval_segments_rb<false>), slice blockIdx.x of gridDim.x of chain blockIdx.y.
+// BearingStream), slice blockIdx.x of chain blockIdx.y (see active_slices).
 __global__ void __launch_bounds__(256) split_eval_rb_kernel(Dev d_by_value) {
   MG_KERNEL_DEV(d);
   __shared__ double red[4];
@@ -1878,7 +1851,7 @@ __global__ void full_ll_kernel(Dev d, uint32_t first, uint32_t Tcur, double* out
     if (tid < nseg) S.segpre[tid + 1] = incl;
     if (tid == 0) S.segpre[0] = 0;
     __syncthreads();
-    acc += d.obear ? eval_segments_rb<true>(d, c, S, nseg) : eval_segments<true>(d, c, S, nseg);
+    acc += d.obear ? full_ll_segments_rb(d, c, S, nseg) : full_ll_segments(d, c, S, nseg);
     __syncthreads();
   }
   const double r = block_sum(acc, S);
