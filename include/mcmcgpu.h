@@ -196,8 +196,9 @@ int mcmcgpu_get_ladders(mcmcgpu_handle h, double* beta, uint32_t* slot_chain, do
                         uint64_t* swaps);
 
 /* mcmcgpu_run with every update issued as a sequence of kernels, the reading
- * stream of each proposal (the loop of mcmc_slam.hpp:476-505) cut into
- * `slices` equal parts that run on different workgroups.  mcmcgpu_run gives a
+ * stream of each proposal (the loop of mcmc_slam.hpp:476-505) cut into up to
+ * `slices` equal parts that run on different workgroups (no part shorter than
+ * 1024 readings: a small proposal takes few workgroups).  mcmcgpu_run gives a
  * chain one workgroup, which is the right shape for hundreds of chains; a
  * single mcmc_slam instance or a handful of tempered replicas on a long
  * trajectory would leave most of the GPU idle.  Same proposals, same accept
