@@ -1696,6 +1696,13 @@ __global__ void commit_kernel(Dev d, uint32_t c, int kind, uint32_t idx, double 
                               double new_weight, double log_ratio, uint32_t Tcur) {
   if (kind == MCMCGPU_STATE_EDGE) {
     const Pose q{q0, q1, q2};
+    double control_part = 0.0;  // what the edge's own control term changes by (kept apart for tempering)
+    if (threadIdx.x == 0) {
+      double mu[3], sd[3];
+      load_control(d, idx, mu, sd);
+      const size_t ri = size_t(c) * d.Tcap + idx;
+      control_part = control_log_pdf(mu, sd, q) - control_log_pdf(mu, sd, Pose{d.relx[ri], d.rely[ri], d.relth[ri]});
+    }
     commit_state_edge(d, c, idx, q, Tcur);
     if (threadIdx.x == 0) {
       const size_t ri = size_t(c) * d.Tcap + idx;
@@ -1704,6 +1711,7 @@ __global__ void commit_kernel(Dev d, uint32_t c, int kind, uint32_t idx, double 
       d.relth[ri] = q.th;
       wt::set(d.sw + size_t(c) * d.Tcap, Tcur, idx, new_weight);
       d.ll[c] += log_ratio;
+      d.llc[c] += control_part;
     }
   } else if (threadIdx.x == 0) {
     const size_t fi = size_t(c) * d.Fcap + idx;

@@ -189,6 +189,11 @@ def test_eval_and_commit_entry_points():
     assert_close(st["state_w"][t], 1.25, 1e-12, "committed state weight")
     assert_close(st["feat_w"][f], 0.75, 1e-12, "committed landmark weight")
     assert_close(g.log_likelihood()[0], g.full_log_likelihood()[0], 1e-9, "incremental vs full after commits")
+    # ... and its split into control part and readings' part (what tempering weighs) tracks a from-scratch one
+    fresh = gpu_handle(p, seeds, trace_capacity=0)
+    fresh.load_state(st["rel"], st["feat_world"])
+    fresh.sync()
+    assert_close(g.ladders()[2][0], fresh.ladders()[2][0], 1e-9, "readings' part of the log likelihood after commits")
     # cumulative poses after the commit equal a from-scratch rebuild
     before = st["cum"].copy()
     g.rebuild()
