@@ -1244,6 +1244,10 @@ int mcmcgpu_import_state(mcmcgpu_handle h, uint32_t chain, const void* dev_in, d
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   if (int rc = rebuild_impl(h)) return rc;
   hipLaunchKernelGGL(reweigh_kernel, dim3(1), dim3(256), 0, h->stream, d, chain, uint32_t(T));
+  // the control part of the log likelihood (kept apart for tempering) from scratch; the total stays
+  // the exporter's figure (the from-scratch total lands in the idle tile-total buffer of the scan)
+  hipLaunchKernelGGL(full_ll_kernel, dim3(1), dim3(h->nthreads), 0, h->stream, d, chain, uint32_t(T),
+                     reinterpret_cast<double*>(h->scan_tot), d.llc);
   HIP_TRY(h, hipGetLastError());
   return 0;
 }

@@ -346,6 +346,8 @@ def test_export_import_moves_a_chain():
     assert_close(s1["feat_w"], s0["feat_w"], 1e-12, "landmark weights of the imported chain", floor=1e-300)
     assert g.log_likelihood()[1] == ll[0]
     assert_close(g.full_log_likelihood()[1], ll[0], 1e-9, "imported chain: incremental vs full log likelihood")
+    rll = g.ladders()[2]  # the readings' part, which tempering weighs, came along too
+    assert_close(rll[1], rll[0], 1e-9, "imported chain: readings' part of the log likelihood")
     g.run(100)  # both keep stepping (with their own generators)
     g.sync()
 
