@@ -1509,15 +1509,11 @@ __global__ void split_commit_kernel(Dev d_by_value, uint32_t Tcur) {
   for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) move_pose(d, base + i, m);
 }
 
-// One lane per landmark: its affected readings and its old and moved position (phases A and B
-// of eval_state_edge, or the single segment of eval_feature_edge); grid = (ceil(nf / 256), chains).
-__global__ void split_setup_kernel(Dev d_by_value, uint32_t Tcur) {
-  MG_KERNEL_DEV(d);
-  const uint32_t c = blockIdx.y, f = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t nf = d.nf[c];
-  if (f >= nf) return;
-  const ChainCtl& k = d.ctl[c];
-  const size_t fi = size_t(c) * d.Fcap + f, si = size_t(c) * (d.Fcap + 1) + f;
+// Landmark f of chain c under the proposal in `k`: first record and number of its affected readings,
+// its position and where the proposal moves it (phases A and B of eval_state_edge, or the single
+// segment of eval_feature_edge).  Returns the count and stores the rest in the split-mode tables.
+MG_DEV uint32_t split_setup_landmark(const Dev& d, uint32_t c, uint32_t f, const ChainCtl& k) {
+  const size_t fi = size_t(c) * d.Fcap + f;
   uint32_t slo = d.foff[f], len = 0;
   Vec2 w{0.0, 0.0}, wn{0.0, 0.0};
   if (k.op == OP_EVAL_STATE) {
@@ -1545,12 +1541,37 @@ __global__ void split_setup_kernel(Dev d_by_value, uint32_t Tcur) {
     len = d.fcnt[fi];
   }
   d.sp_seglo[fi] = slo;
-  d.sp_segpre[si] = len;
   double* o = d.sp_segw + 4 * fi;
   o[0] = w.x;
   o[1] = w.y;
   o[2] = wn.x;
   o[3] = wn.y;
+  return len;
+}
+
+// One lane per landmark; grid = (ceil(nf / 256), chains).  Leaves the counts for split_scan_kernel.
+__global__ void split_setup_kernel(Dev d_by_value) {
+  MG_KERNEL_DEV(d);
+  const uint32_t c = blockIdx.y, f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= d.nf[c]) return;
+  d.sp_segpre[size_t(c) * (d.Fcap + 1) + f] = split_setup_landmark(d, c, f, d.ctl[c]);
+}
+
+// The same and the prefix sums in one kernel, for chains of at most blockDim.x (1024) landmarks:
+// one launch and one pass through memory fewer per update.  grid = chains.
+__global__ void __launch_bounds__(1024) split_setup_scan_kernel(Dev d_by_value) {
+  MG_KERNEL_DEV(d);
+  __shared__ Shared S;
+  const uint32_t c = blockIdx.x, f = threadIdx.x, nf = d.nf[c];
+  const uint32_t len = f < nf ? split_setup_landmark(d, c, f, d.ctl[c]) : 0;
+  uint32_t total;
+  const uint32_t incl = block_scan_u32(len, S, total);
+  uint32_t* pre = d.sp_segpre + size_t(c) * (d.Fcap + 1);
+  if (f < nf) pre[f] = incl - len;
+  if (f == 0) {
+    pre[nf] = total;
+    d.ctl[c].total = total;
+  }
 }
 
 // Counts -> exclusive prefix sums, in place; grid = chains.

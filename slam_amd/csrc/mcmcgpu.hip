@@ -858,8 +858,12 @@ int mcmcgpu_run_split(mcmcgpu_handle h, uint32_t steps, uint32_t slices) {
   const uint32_t pieces = std::max<uint32_t>(1, std::min<uint32_t>(64, (T + 4095) / 4096));
   if (steps) hipLaunchKernelGGL(split_ends_kernel, dim3(C), dim3(256), 0, h->stream, h->d, T, slices, 0u, 1u, defer);
   for (uint32_t i = 0; i < steps; ++i) {
-    hipLaunchKernelGGL(split_setup_kernel, dim3(fblocks, C), dim3(256), 0, h->stream, h->d, T);
-    hipLaunchKernelGGL(split_scan_kernel, dim3(C), dim3(256), 0, h->stream, h->d);
+    if (h->d.F <= 1024) {
+      hipLaunchKernelGGL(split_setup_scan_kernel, dim3(C), dim3(1024), 0, h->stream, h->d);
+    } else {
+      hipLaunchKernelGGL(split_setup_kernel, dim3(fblocks, C), dim3(256), 0, h->stream, h->d);
+      hipLaunchKernelGGL(split_scan_kernel, dim3(C), dim3(256), 0, h->stream, h->d);
+    }
     if (h->cfg.range_bearing)
       hipLaunchKernelGGL(split_eval_rb_kernel, dim3(slices, C), dim3(256), 0, h->stream, h->d);
     else

@@ -891,3 +891,24 @@ def test_split_mode_with_the_pose_update_as_a_kernel_of_its_own():
             assert np.array_equal(a[name], b[name]), name
     for a, b in zip(out[0][2:], out[1][2:]):
         assert np.array_equal(a, b)
+
+
+def test_split_mode_with_more_landmarks_than_one_workgroup_prepares():
+    """More than 1024 landmarks: the segments are prepared by several workgroups per chain and the
+    prefix sums by a kernel of their own (up to 1024 one kernel does both)."""
+    p = synthetic.make_problem(T=1500, n_landmarks=1400, k_nearest=8, seed=3, lap_steps=150, wobble_period=500,
+                               range_stddev=2.0, landmark_spread=6.0)
+    assert p["F"] > 1024
+    seeds = capi.seed_sequence(4321, 2)
+    steps = 150
+    w = oracle_world(p, seeds)
+    w.replay(p["T"])
+    g = gpu_handle(p, seeds, trace_capacity=4096, max_split_slices=8)
+    g.grow(p["T"])
+    g.run_split(steps, 8)
+    g.sync()
+    ll = g.log_likelihood()
+    for c in range(len(seeds)):
+        assert w.update(c, steps) >= 0
+        compare_traces(g.trace(c), w.trace(c), abs(w.log_likelihood(c)))
+        assert_close(ll[c], w.log_likelihood(c), REL, f"chain {c} final log likelihood")
