@@ -104,6 +104,7 @@ struct Dev {
   uint32_t* sp_segpre;   // [C][Fcap+1] their count, then (after the scan) the prefix sums
   double* sp_segw;       // [C][Fcap][4] old and moved landmark position
   double* sp_partial;    // [C][max_slices]
+  uint32_t* sp_slice_seg;  // [C][max_slices+1] segment of each slice's first reading; entry n = last segment
   uint32_t max_slices;
 };
 
@@ -129,9 +130,37 @@ constexpr uint32_t kMaxRetry = 1u << 16;
 // list) occupies a few workgroups, a large one all of them.  It depends on the chain's own
 // proposal only, so a chain's arithmetic does not depend on which other chains share the launch.
 constexpr uint32_t kSplitMinChunk = 1024;
+constexpr uint32_t kSplitWindow = 1024;  // segments of one slice whose prefix sums are staged in LDS
 __device__ __forceinline__ uint32_t active_slices(uint32_t total, uint32_t offered) {
   const uint32_t n = (total + kSplitMinChunk - 1) / kSplitMinChunk;
   return n < 1 ? 1 : (n > offered ? offered : n);
+}
+
+// Segment (landmark) that holds the first reading of every slice of a chain's stream, found in the
+// exclusive prefix sums `pre_at(0 .. nf-1)`; entry `n` (one past the last slice) is the last
+// segment.  The stream kernel stages the prefix sums of its own segments [entry s, entry s+1] in
+// LDS instead of searching all of them in global memory.
+template <class PreAt>
+__device__ __forceinline__ void write_slice_segments(uint32_t* out, uint32_t nf, uint32_t total, uint32_t offered,
+                                                     PreAt pre_at) {
+  const uint32_t n = active_slices(total, offered), per = (total + n - 1) / n;
+  for (uint32_t s = threadIdx.x; s <= n; s += blockDim.x) {
+    uint32_t a = 0;
+    if (s == n) {
+      a = nf ? nf - 1 : 0;
+    } else if (nf) {  // last f with pre[f] <= i
+      const uint32_t i = s * per;
+      uint32_t b = nf;
+      while (a + 1 < b) {
+        const uint32_t m = (a + b) >> 1;
+        if (pre_at(m) <= i)
+          a = m;
+        else
+          b = m;
+      }
+    }
+    out[s] = a;
+  }
 }
 
 enum Op : int { OP_END = 0, OP_EVAL_STATE = 1, OP_EVAL_FEATURE = 2 };
@@ -1559,7 +1588,7 @@ __global__ void split_setup_kernel(Dev d_by_value) {
 
 // The same and the prefix sums in one kernel, for chains of at most blockDim.x (1024) landmarks:
 // one launch and one pass through memory fewer per update.  grid = chains.
-__global__ void __launch_bounds__(1024) split_setup_scan_kernel(Dev d_by_value) {
+__global__ void __launch_bounds__(1024) split_setup_scan_kernel(Dev d_by_value, uint32_t slices) {
   MG_KERNEL_DEV(d);
   __shared__ Shared S;
   const uint32_t c = blockIdx.x, f = threadIdx.x, nf = d.nf[c];
@@ -1567,15 +1596,21 @@ __global__ void __launch_bounds__(1024) split_setup_scan_kernel(Dev d_by_value) 
   uint32_t total;
   const uint32_t incl = block_scan_u32(len, S, total);
   uint32_t* pre = d.sp_segpre + size_t(c) * (d.Fcap + 1);
-  if (f < nf) pre[f] = incl - len;
+  if (f < nf) {
+    pre[f] = incl - len;
+    S.act[f] = incl - len;  // kActCap = 1024 entries
+  }
   if (f == 0) {
     pre[nf] = total;
     d.ctl[c].total = total;
   }
+  __syncthreads();
+  write_slice_segments(d.sp_slice_seg + size_t(c) * (d.max_slices + 1), nf, total, slices,
+                       [](uint32_t m) { return S.act[m]; });
 }
 
 // Counts -> exclusive prefix sums, in place; grid = chains.
-__global__ void split_scan_kernel(Dev d_by_value) {
+__global__ void split_scan_kernel(Dev d_by_value, uint32_t slices) {
   MG_KERNEL_DEV(d);
   __shared__ Shared S;
   const uint32_t c = blockIdx.x, nf = d.nf[c];
@@ -1593,6 +1628,10 @@ __global__ void split_scan_kernel(Dev d_by_value) {
     pre[nf] = carry;
     d.ctl[c].total = carry;
   }
+  __syncthreads();  // the prefix sums written above are read back by other lanes below
+  const uint32_t* cpre = pre;
+  write_slice_segments(d.sp_slice_seg + size_t(c) * (d.max_slices + 1), nf, carry, slices,
+                       [cpre](uint32_t m) { return cpre[m]; });
 }
 
 // The reading stream of one proposal, slice blockIdx.x of chain blockIdx.y (see active_slices).
@@ -1601,6 +1640,7 @@ __global__ void split_scan_kernel(Dev d_by_value) {
 __global__ void __launch_bounds__(256) split_eval_kernel(Dev d_by_value) {
   MG_KERNEL_DEV(d);
   __shared__ double red[4];
+  __shared__ uint32_t wpre[kSplitWindow + 1], wlo[kSplitWindow];
   const uint32_t c = blockIdx.y, nf = d.nf[c];
   const uint32_t* __restrict__ segpre = d.sp_segpre + size_t(c) * (d.Fcap + 1);
   const uint32_t* __restrict__ seglo = d.sp_seglo + size_t(c) * d.Fcap;
@@ -1612,24 +1652,42 @@ __global__ void __launch_bounds__(256) split_eval_kernel(Dev d_by_value) {
   if (blockIdx.x >= slices) return;
   const uint32_t per = (total + slices - 1) / slices;
   const uint32_t lo = min(total, blockIdx.x * per), hi = min(total, lo + per);
-  double acc = 0.0;
-  if (lo + threadIdx.x < hi) {
+  // this slice's segments [seg0, seg0 + nwin): their prefix sums and first records go to LDS when
+  // they fit, so that the search for a lane's first segment and the cursor after it stay out of
+  // global memory
+  const uint32_t* sseg = d.sp_slice_seg + size_t(c) * (d.max_slices + 1);
+  uint32_t seg0 = sseg[blockIdx.x], nwin = sseg[blockIdx.x + 1] - seg0 + 1;
+  const bool staged = nwin <= kSplitWindow;
+  if (staged) {
+    for (uint32_t j = threadIdx.x; j <= nwin; j += 256) wpre[j] = segpre[seg0 + j];
+    for (uint32_t j = threadIdx.x; j < nwin; j += 256) wlo[j] = seglo[seg0 + j];
+    __syncthreads();
+  } else {
+    seg0 = 0;
+    nwin = nf;
+  }
+  const uint32_t fallback_record = seglo[0];
+  const bool usig = d.usig_inv > 0.0;
+  const double half_isd2 = 0.5 * d.usig_inv * d.usig_inv;
+  const double* __restrict__ oisd = d.oisd;
+  // pre_at(j), lo_at(j): prefix sum and first record of segment seg0 + j
+  auto stream = [&](auto pre_at, auto lo_at) {
+    double acc = 0.0;
+    if (lo + threadIdx.x >= hi) return acc;
     uint32_t cur;
-    {  // the segment that holds this lane's first reading: last f with segpre[f] <= i
-      uint32_t a = 0, b = nf;
+    {  // the segment that holds this lane's first reading: last j with pre_at(j) <= i
+      uint32_t a = 0, b = nwin;
       const uint32_t i = lo + threadIdx.x;
       while (a + 1 < b) {
         const uint32_t m = (a + b) >> 1;
-        if (segpre[m] <= i)
+        if (pre_at(m) <= i)
           a = m;
         else
           b = m;
       }
       cur = a;
     }
-    uint32_t seg_end = segpre[cur + 1], seg_base = seglo[cur] - segpre[cur];
-    const bool usig = d.usig_inv > 0.0;
-    const double half_isd2 = 0.5 * d.usig_inv * d.usig_inv;
+    uint32_t seg_end = pre_at(cur + 1), seg_base = lo_at(cur) - pre_at(cur);
     constexpr int U = 2;
     constexpr uint32_t stride = 256;
     ObsRec rec[U];
@@ -1641,14 +1699,14 @@ __global__ void __launch_bounds__(256) split_eval_kernel(Dev d_by_value) {
         if (i < hi) {
           while (i >= seg_end) {
             ++cur;
-            seg_end = segpre[cur + 1];
-            seg_base = seglo[cur] - segpre[cur];
+            seg_end = pre_at(cur + 1);
+            seg_base = lo_at(cur) - pre_at(cur);
           }
           o[u] = seg_base + i;
         } else {
-          o[u] = seglo[0];
+          o[u] = fallback_record;
         }
-        sg[u] = cur;
+        sg[u] = seg0 + cur;
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) rec[u] = orec[o[u]];
@@ -1665,7 +1723,7 @@ __global__ void __launch_bounds__(256) split_eval_kernel(Dev d_by_value) {
         s_[u] = sg[u];
         k[u] = half_isd2;
         if (!usig) {
-          const double isd = d.oisd[o[u]];
+          const double isd = oisd[o[u]];
           k[u] = 0.5 * isd * isd;
         }
       }
@@ -1679,7 +1737,10 @@ __global__ void __launch_bounds__(256) split_eval_kernel(Dev d_by_value) {
         if (i0 + u * stride < hi) acc += term;
       }
     }
-  }
+    return acc;
+  };
+  double acc = staged ? stream([&](uint32_t j) { return wpre[j]; }, [&](uint32_t j) { return wlo[j]; })
+                      : stream([&](uint32_t j) { return segpre[j]; }, [&](uint32_t j) { return seglo[j]; });
 #pragma unroll
   for (int dd = 32; dd > 0; dd >>= 1) acc += __shfl_down(acc, dd);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;

@@ -409,6 +409,7 @@ int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out) {
     ALLOC(d.sp_segpre, C * (size_t(d.Fcap) + 1));
     ALLOC(d.sp_segw, 4 * C * d.Fcap);
     ALLOC(d.sp_partial, C * d.max_slices);
+    ALLOC(d.sp_slice_seg, C * (size_t(d.max_slices) + 1));
   }
   h->snap_doubles = 3 * size_t(d.Tcap) + 2 * size_t(d.Fcap) + 2;
   ALLOC(h->snap_dev, h->snap_doubles);
@@ -859,10 +860,10 @@ int mcmcgpu_run_split(mcmcgpu_handle h, uint32_t steps, uint32_t slices) {
   if (steps) hipLaunchKernelGGL(split_ends_kernel, dim3(C), dim3(256), 0, h->stream, h->d, T, slices, 0u, 1u, defer);
   for (uint32_t i = 0; i < steps; ++i) {
     if (h->d.F <= 1024) {
-      hipLaunchKernelGGL(split_setup_scan_kernel, dim3(C), dim3(1024), 0, h->stream, h->d);
+      hipLaunchKernelGGL(split_setup_scan_kernel, dim3(C), dim3(1024), 0, h->stream, h->d, slices);
     } else {
       hipLaunchKernelGGL(split_setup_kernel, dim3(fblocks, C), dim3(256), 0, h->stream, h->d);
-      hipLaunchKernelGGL(split_scan_kernel, dim3(C), dim3(256), 0, h->stream, h->d);
+      hipLaunchKernelGGL(split_scan_kernel, dim3(C), dim3(256), 0, h->stream, h->d, slices);
     }
     if (h->cfg.range_bearing)
       hipLaunchKernelGGL(split_eval_rb_kernel, dim3(slices, C), dim3(256), 0, h->stream, h->d);

@@ -893,9 +893,11 @@ def test_split_mode_with_the_pose_update_as_a_kernel_of_its_own():
         assert np.array_equal(a, b)
 
 
-def test_split_mode_with_more_landmarks_than_one_workgroup_prepares():
+@pytest.mark.parametrize("slices", [8, 1])
+def test_split_mode_with_more_landmarks_than_one_workgroup_prepares(slices):
     """More than 1024 landmarks: the segments are prepared by several workgroups per chain and the
-    prefix sums by a kernel of their own (up to 1024 one kernel does both)."""
+    prefix sums by a kernel of their own (up to 1024 one kernel does both).  With a single slice the
+    stream kernel meets more segments than it stages in LDS and walks the tables in global memory."""
     p = synthetic.make_problem(T=1500, n_landmarks=1400, k_nearest=8, seed=3, lap_steps=150, wobble_period=500,
                                range_stddev=2.0, landmark_spread=6.0)
     assert p["F"] > 1024
@@ -905,7 +907,7 @@ def test_split_mode_with_more_landmarks_than_one_workgroup_prepares():
     w.replay(p["T"])
     g = gpu_handle(p, seeds, trace_capacity=4096, max_split_slices=8)
     g.grow(p["T"])
-    g.run_split(steps, 8)
+    g.run_split(steps, slices)
     g.sync()
     ll = g.log_likelihood()
     for c in range(len(seeds)):
