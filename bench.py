@@ -230,8 +230,7 @@ def main():
 
     def one_step(i):
         if args.split_slices:
-            g.run_split(args.updates_per_step, args.split_slices)
-            g.write_summaries(summaries[-1].data_ptr())  # one record per chain at the end of the step
+            g.run_split_reported(args.updates_per_step, args.split_slices, args.report_every, summaries.data_ptr())
         else:
             g.run_reported(args.updates_per_step, args.report_every, summaries.data_ptr())
         if args.rebuild_every and (i + 1) % args.rebuild_every == 0:

@@ -207,6 +207,12 @@ int mcmcgpu_get_ladders(mcmcgpu_handle h, double* beta, uint32_t* slot_chain, do
  * slices <= max_split_slices of the config. */
 int mcmcgpu_run_split(mcmcgpu_handle h, uint32_t steps, uint32_t slices);
 
+/* mcmcgpu_run_split with the report records of mcmcgpu_run_reported: after every
+ * report_every updates (and after the last) every chain's summary goes to row k
+ * of dev_out ([intervals][chains] records in device memory), or to the library's
+ * own buffer when dev_out is NULL (mcmcgpu_get_reports). */
+int mcmcgpu_run_split_reported(mcmcgpu_handle h, uint32_t steps, uint32_t slices, uint32_t report_every, void* dev_out);
+
 /* edge_log_likelihood_ratio (mcmc_slam.hpp:432-474) for one given proposal on
  * one chain, without changing the chain.  For a state edge the value includes
  * the control term (:436-438). */

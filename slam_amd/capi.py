@@ -63,6 +63,7 @@ EXPORTS = [
     "mcmcgpu_run_reported",
     "mcmcgpu_get_reports",
     "mcmcgpu_run_split",
+    "mcmcgpu_run_split_reported",
     "mcmcgpu_set_ladders",
     "mcmcgpu_exchange",
     "mcmcgpu_get_ladders",
@@ -256,6 +257,14 @@ class McmcGpu:
     def run_split(self, steps, slices):
         """`steps` updates per chain, each proposal's reading stream cut into `slices` workgroups."""
         self._check(self.lib.mcmcgpu_run_split(self.h, ctypes.c_uint32(steps), ctypes.c_uint32(slices)), "mcmcgpu_run_split")
+
+    def run_split_reported(self, steps, slices, report_every, dev_ptr):
+        """run_split that leaves the summaries of run_reported at every interval boundary."""
+        self._check(
+            self.lib.mcmcgpu_run_split_reported(self.h, ctypes.c_uint32(steps), ctypes.c_uint32(slices),
+                                                ctypes.c_uint32(report_every),
+                                                ctypes.c_void_p(dev_ptr) if dev_ptr else None),
+            "mcmcgpu_run_split_reported")
 
     def get_reports(self):
         """Records of the last run_reported(..., dev_ptr=None): structured array [intervals, C]."""

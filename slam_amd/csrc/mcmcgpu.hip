@@ -838,6 +838,10 @@ int mcmcgpu_get_ladders(mcmcgpu_handle h, double* beta, uint32_t* slot_chain, do
 }
 
 int mcmcgpu_run_split(mcmcgpu_handle h, uint32_t steps, uint32_t slices) {
+  return mcmcgpu_run_split_reported(h, steps, slices, 0, nullptr);
+}
+
+int mcmcgpu_run_split_reported(mcmcgpu_handle h, uint32_t steps, uint32_t slices, uint32_t report_every, void* dev_out) {
   if (!h) return MCMCGPU_ERR_ARGUMENT;
   if (!h->problem_loaded || h->chains == 0) return fail(h, MCMCGPU_ERR_STATE, "upload a problem and init chains first");
   if (h->next_timestep == 0) return fail(h, MCMCGPU_ERR_STATE, "chains have not processed timestep 0 yet");
@@ -845,6 +849,18 @@ int mcmcgpu_run_split(mcmcgpu_handle h, uint32_t steps, uint32_t slices) {
   if (slices == 0 || slices > h->d.max_slices) return fail(h, MCMCGPU_ERR_ARGUMENT, "slices out of range");
   if (h->cfg.range_bearing && !h->bearings_loaded)
     return fail(h, MCMCGPU_ERR_STATE, "mcmcgpu_set_bearings must follow mcmcgpu_upload_problem on a range-and-bearing handle");
+  mcmcgpu_chain_summary* reports = nullptr;  // one row of C records per report interval
+  if (report_every) {
+    const uint32_t intervals = (steps + report_every - 1) / report_every;
+    reports = static_cast<mcmcgpu_chain_summary*>(dev_out);
+    if (!reports) {  // the library's own buffer, read back with mcmcgpu_get_reports
+      if (intervals > kMaxOwnReports)
+        return fail(h, MCMCGPU_ERR_CAPACITY, "more report intervals than the library's buffer holds (" +
+                                                 std::to_string(kMaxOwnReports) + "); pass a buffer or split the run");
+      reports = h->reports;
+      h->report_intervals = intervals;
+    }
+  }
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   const uint32_t T = edges_grown(h), C = h->chains;
   const uint32_t fblocks = std::max<uint32_t>(1, (h->d.F + 255) / 256);
@@ -872,6 +888,9 @@ int mcmcgpu_run_split(mcmcgpu_handle h, uint32_t steps, uint32_t slices) {
     hipLaunchKernelGGL(split_ends_kernel, dim3(C), dim3(256), 0, h->stream, h->d, T, slices, 1u, i + 1 < steps ? 1u : 0u,
                        defer);
     if (defer) hipLaunchKernelGGL(split_commit_kernel, dim3(pieces, C), dim3(256), 0, h->stream, h->d, T);
+    if (reports && ((i + 1) % report_every == 0 || i + 1 == steps))  // the chains' summaries at an interval boundary
+      hipLaunchKernelGGL(summaries_kernel, dim3((C + 255) / 256), dim3(256), 0, h->stream, h->d,
+                         reports + size_t(i / report_every) * C);
     if ((launch_error = hipGetLastError()) != hipSuccess) break;
   }
   return end_timed(h, ev, launch_error, "split-mode launch");

@@ -914,3 +914,21 @@ def test_split_mode_with_more_landmarks_than_one_workgroup_prepares(slices):
         assert w.update(c, steps) >= 0
         compare_traces(g.trace(c), w.trace(c), abs(w.log_likelihood(c)))
         assert_close(ll[c], w.log_likelihood(c), REL, f"chain {c} final log likelihood")
+
+
+def test_split_mode_leaves_the_report_records_of_a_reported_launch():
+    """mcmcgpu_run_split_reported against mcmcgpu_run_reported: the same summary per chain and interval."""
+    p = small_problem(T=300, F=12, k=4, seed=7)
+    seeds = capi.seed_sequence(90, 3)
+    a = gpu_handle(p, seeds, trace_capacity=0)
+    a.grow(p["T"])
+    a.run_reported(250, 100, None)
+    ra = a.get_reports()
+    b = gpu_handle(p, seeds, trace_capacity=0, max_split_slices=4)
+    b.grow(p["T"])
+    b.run_split_reported(250, 4, 100, None)
+    rb = b.get_reports()
+    assert ra.shape == rb.shape == (3, 3)
+    assert np.array_equal(ra["updates"], rb["updates"]) and np.array_equal(ra["accepts"], rb["accepts"])
+    assert_close(rb["log_likelihood"], ra["log_likelihood"], REL, "log likelihoods at the interval boundaries")
+    assert list(ra["updates"][:, 0]) == [100, 200, 250]

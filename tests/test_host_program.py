@@ -245,3 +245,22 @@ def test_single_chain_split_mode_gives_the_same_run():
         out = run(*args, *extra)
         lls.append(float([ln for ln in out.splitlines() if ln.startswith("MCMC-SLAM log likelihood")][0].split()[-1]))
     assert abs(lls[0] - lls[1]) <= 1e-9 * abs(lls[0]), lls
+
+
+@pytest.mark.gpu
+def test_multi_mcmc_with_few_chains_in_split_mode_writes_the_same_report(tmp_path):
+    """--multi-mcmc with a handful of chains switches to split mode on large data (forced on here): the
+    report lines are those of the one-workgroup-per-chain run."""
+    reports = []
+    for k, extra in enumerate((["--split-slices", "0"], ["--split-slices", "4", "--split-min-observations", "1"])):
+        d = tmp_path / str(k)
+        d.mkdir()
+        out = subprocess.run([EXE, "--dataset", "Plaza2", "--dataset-dir", PLAZA, "--multi-mcmc", "--multi-mcmc-chains", "6",
+                              "--multi-mcmc-end-steps", "250", "--sensor-range-stddev", "4", "--seed", "7", *extra],
+                             capture_output=True, text=True, timeout=600, cwd=d)
+        assert out.returncode == 0, out.stdout + out.stderr
+        reports.append([[float(x) for x in ln.split("\t")] for ln in open(d / "multi-mcmc-report.txt").read().splitlines()])
+    assert len(reports[0]) == len(reports[1]) == 3
+    for a, b in zip(*reports):
+        assert a[0] == b[0] and a[1] == b[1]  # updates and accepts per chain
+        assert abs(a[2] - b[2]) <= 1e-9 * abs(a[2])  # best log likelihood
