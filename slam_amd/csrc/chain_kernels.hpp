@@ -1388,71 +1388,6 @@ MG_DEV void shared_to_ctl(const Dev& d, uint32_t c, const Shared& S) {
   k.use_weight = S.use_weight;
 }
 
-// The reading stream of one proposal for range-and-bearing readings (the arithmetic of
-// BearingStream), slice blockIdx.x of chain blockIdx.y (see active_slices).
-__global__ void __launch_bounds__(256) split_eval_rb_kernel(Dev d_by_value) {
-  MG_KERNEL_DEV(d);
-  __shared__ double red[4];
-  const uint32_t c = blockIdx.y, nf = d.nf[c];
-  const uint32_t* __restrict__ segpre = d.sp_segpre + size_t(c) * (d.Fcap + 1);
-  const uint32_t* __restrict__ seglo = d.sp_seglo + size_t(c) * d.Fcap;
-  const double* __restrict__ w4 = d.sp_segw + 4 * size_t(c) * d.Fcap;
-  const PoseXY* __restrict__ poses = d.pxy + size_t(c) * (d.Tcap + 1);
-  const double* __restrict__ pth = d.pth + size_t(c) * (d.Tcap + 1);
-  const uint32_t total = nf ? segpre[nf] : 0;
-  const uint32_t slices = active_slices(total, gridDim.x);
-  if (blockIdx.x >= slices) return;
-  const uint32_t per = (total + slices - 1) / slices;
-  const uint32_t lo = min(total, blockIdx.x * per), hi = min(total, lo + per);
-  const bool usig = d.usig_inv > 0.0 && d.ubsig_inv > 0.0;
-  const double half_isd2 = 0.5 * d.usig_inv * d.usig_inv, half_ibsd2 = 0.5 * d.ubsig_inv * d.ubsig_inv;
-  double acc = 0.0;
-  if (lo + threadIdx.x < hi) {
-    uint32_t cur;
-    {
-      uint32_t a = 0, b = nf;
-      const uint32_t i = lo + threadIdx.x;
-      while (a + 1 < b) {
-        const uint32_t m = (a + b) >> 1;
-        if (segpre[m] <= i)
-          a = m;
-        else
-          b = m;
-      }
-      cur = a;
-    }
-    uint32_t seg_end = segpre[cur + 1], seg_base = seglo[cur] - segpre[cur];
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
-      while (i >= seg_end) {
-        ++cur;
-        seg_end = segpre[cur + 1];
-        seg_base = seglo[cur] - segpre[cur];
-      }
-      const uint32_t o = seg_base + i;
-      const ObsRec rec = d.orec[o];
-      const double bm = d.obear[o];
-      double kr = half_isd2, kb = half_ibsd2;
-      if (!usig) {
-        const double isd = d.oisd[o], ibsd = d.obisd[o];
-        kr = 0.5 * isd * isd;
-        kb = 0.5 * ibsd * ibsd;
-      }
-      const PoseXY p = poses[rec.t];
-      const double th = pth[rec.t];
-      const double* w = w4 + 4 * size_t(cur);
-      const double ox = w[0] - p.x, oy = w[1] - p.y, nx = w[2] - p.x, ny = w[3] - p.y;
-      const double ro = range_of(ox, oy), rn = range_of(nx, ny);
-      const double eo = wrap_residual(atan2(oy, ox) - th - bm), en = wrap_residual(atan2(ny, nx) - th - bm);
-      acc += (ro - rn) * fma(-2.0, rec.mu, ro + rn) * kr + (eo - en) * (eo + en) * kb;
-    }
-  }
-#pragma unroll
-  for (int dd = 32; dd > 0; dd >>= 1) acc += __shfl_down(acc, dd);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) d.sp_partial[size_t(c) * d.max_slices + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-}
-
 // The serial ends of an update, one workgroup per chain: the END of update k -- sum of the slices,
 // accept test (mcmc_slam.hpp:385-418), pose table of an accepted state edge -- and the BEGINNING of
 // update k + 1 -- selection and proposal (:339-382) -- in one kernel, so that the chain's generator
@@ -1636,7 +1571,9 @@ __global__ void split_scan_kernel(Dev d_by_value, uint32_t slices) {
 
 // The reading stream of one proposal, slice blockIdx.x of chain blockIdx.y (see active_slices).
 // Two readings per lane per group; the records of the next group are requested before the
-// current group is evaluated, so that their latency hides behind its arithmetic.
+// current group is evaluated, so that their latency hides behind its arithmetic.  BEAR: range-and-
+// bearing readings (the arithmetic of BearingStream).
+template <bool BEAR>
 __global__ void __launch_bounds__(256) split_eval_kernel(Dev d_by_value) {
   MG_KERNEL_DEV(d);
   __shared__ double red[4];
@@ -1646,7 +1583,9 @@ __global__ void __launch_bounds__(256) split_eval_kernel(Dev d_by_value) {
   const uint32_t* __restrict__ seglo = d.sp_seglo + size_t(c) * d.Fcap;
   const double* __restrict__ w4 = d.sp_segw + 4 * size_t(c) * d.Fcap;
   const PoseXY* __restrict__ poses = d.pxy + size_t(c) * (d.Tcap + 1);
+  const double* __restrict__ pth = d.pth + size_t(c) * (d.Tcap + 1);
   const ObsRec* __restrict__ orec = d.orec;
+  const double* __restrict__ obear = d.obear;
   const uint32_t total = nf ? segpre[nf] : 0;
   const uint32_t slices = active_slices(total, gridDim.x);
   if (blockIdx.x >= slices) return;
@@ -1667,9 +1606,11 @@ __global__ void __launch_bounds__(256) split_eval_kernel(Dev d_by_value) {
     nwin = nf;
   }
   const uint32_t fallback_record = seglo[0];
-  const bool usig = d.usig_inv > 0.0;
-  const double half_isd2 = 0.5 * d.usig_inv * d.usig_inv;
+  // one sigma for all ranges (and, with bearings, one for all bearings): nothing to load per reading
+  const bool usig = d.usig_inv > 0.0 && (!BEAR || d.ubsig_inv > 0.0);
+  const double half_isd2 = 0.5 * d.usig_inv * d.usig_inv, half_ibsd2 = 0.5 * d.ubsig_inv * d.ubsig_inv;
   const double* __restrict__ oisd = d.oisd;
+  const double* __restrict__ obisd = d.obisd;
   // pre_at(j), lo_at(j): prefix sum and first record of segment seg0 + j
   auto stream = [&](auto pre_at, auto lo_at) {
     double acc = 0.0;
@@ -1691,6 +1632,7 @@ __global__ void __launch_bounds__(256) split_eval_kernel(Dev d_by_value) {
     constexpr int U = 2;
     constexpr uint32_t stride = 256;
     ObsRec rec[U];
+    double bm[U];
     uint32_t o[U], sg[U];
     auto fetch = [&](uint32_t i0) {
 #pragma unroll
@@ -1709,12 +1651,15 @@ __global__ void __launch_bounds__(256) split_eval_kernel(Dev d_by_value) {
         sg[u] = seg0 + cur;
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u) rec[u] = orec[o[u]];
+      for (int u = 0; u < U; ++u) {
+        rec[u] = orec[o[u]];
+        if (BEAR) bm[u] = obear[o[u]];
+      }
     };
     fetch(lo + threadIdx.x);
     for (uint32_t i0 = lo + threadIdx.x; i0 < hi; i0 += U * stride) {
       PoseXY p[U];
-      double mu[U], k[U];
+      double mu[U], k[U], th[U], bmu[U], kb[U];
       uint32_t s_[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -1722,18 +1667,32 @@ __global__ void __launch_bounds__(256) split_eval_kernel(Dev d_by_value) {
         mu[u] = rec[u].mu;
         s_[u] = sg[u];
         k[u] = half_isd2;
+        if (BEAR) {
+          th[u] = pth[rec[u].t];
+          bmu[u] = bm[u];
+          kb[u] = half_ibsd2;
+        }
         if (!usig) {
           const double isd = oisd[o[u]];
           k[u] = 0.5 * isd * isd;
+          if (BEAR) {
+            const double ibsd = obisd[o[u]];
+            kb[u] = 0.5 * ibsd * ibsd;
+          }
         }
       }
       if (i0 + U * stride < hi) fetch(i0 + U * stride);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const double* w = w4 + 4 * size_t(s_[u]);
-        const double ro = range_of(w[0] - p[u].x, w[1] - p[u].y);
-        const double rn = range_of(w[2] - p[u].x, w[3] - p[u].y);
-        const double term = (ro - rn) * fma(-2.0, mu[u], ro + rn) * k[u];
+        const double ox = w[0] - p[u].x, oy = w[1] - p[u].y, nx = w[2] - p[u].x, ny = w[3] - p[u].y;
+        const double ro = range_of(ox, oy), rn = range_of(nx, ny);
+        double term = (ro - rn) * fma(-2.0, mu[u], ro + rn) * k[u];
+        if (BEAR) {
+          const double eo = wrap_residual(atan2(oy, ox) - th[u] - bmu[u]);
+          const double en = wrap_residual(atan2(ny, nx) - th[u] - bmu[u]);
+          term = term + (eo - en) * (eo + en) * kb[u];
+        }
         if (i0 + u * stride < hi) acc += term;
       }
     }

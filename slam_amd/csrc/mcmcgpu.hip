@@ -882,9 +882,9 @@ int mcmcgpu_run_split_reported(mcmcgpu_handle h, uint32_t steps, uint32_t slices
       hipLaunchKernelGGL(split_scan_kernel, dim3(C), dim3(256), 0, h->stream, h->d, slices);
     }
     if (h->cfg.range_bearing)
-      hipLaunchKernelGGL(split_eval_rb_kernel, dim3(slices, C), dim3(256), 0, h->stream, h->d);
+      hipLaunchKernelGGL(split_eval_kernel<true>, dim3(slices, C), dim3(256), 0, h->stream, h->d);
     else
-      hipLaunchKernelGGL(split_eval_kernel, dim3(slices, C), dim3(256), 0, h->stream, h->d);
+      hipLaunchKernelGGL(split_eval_kernel<false>, dim3(slices, C), dim3(256), 0, h->stream, h->d);
     hipLaunchKernelGGL(split_ends_kernel, dim3(C), dim3(256), 0, h->stream, h->d, T, slices, 1u, i + 1 < steps ? 1u : 0u,
                        defer);
     if (defer) hipLaunchKernelGGL(split_commit_kernel, dim3(pieces, C), dim3(256), 0, h->stream, h->d, T);
