@@ -293,13 +293,15 @@ def main():
                       "chains, range-and-bearing readings" if bearing else "chains"))
     if rank == 0:
         traffic = None  # PMC counters cannot be read from inside this process: the last profiling round's figure
-        try:
-            with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
-                rec = json.load(f)
-            if rec["updates_per_step"] == args.updates_per_step and rec["workload"] == workload_name:
-                traffic = rec["traffic_bytes_per_launch"]
-        except (OSError, ValueError, KeyError):
-            pass
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "hbm_traffic*.json"))):
+            try:
+                with open(path) as f:
+                    rec = json.load(f)
+                if rec["updates_per_step"] == args.updates_per_step and rec["workload"] == workload_name:
+                    traffic = rec["traffic_bytes_per_launch"]
+            except (OSError, ValueError, KeyError):
+                pass
         # a range-and-bearing reading also needs the pose's angle and the measured bearing: 48 bytes
         unit_bytes = BYTES_PER_UNIT + 16 if bearing else BYTES_PER_UNIT
         bytes_per_launch = (d_units * unit_bytes + d_state * F * BYTES_PER_LANDMARK +
