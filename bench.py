@@ -45,6 +45,9 @@ def parse_args():
                          "range-bearing: the headline workload with the reference's other observation model (48 B per unit)")
     ap.add_argument("--bearing-stddev", type=float, default=0.05, help="range-bearing: sigma of the bearings, rad")
     ap.add_argument("--chains", type=int, default=None, help="chains per GPU (1024; tempering: 64)")
+    ap.add_argument("--total-chains", type=int, default=0,
+                    help="chains of the whole job, divided over the GPUs (strong scaling: 8192 over 2/4/8 GPUs is "
+                         "the sharded configuration of the baseline); overrides --chains")
     ap.add_argument("--updates-per-step", type=int, default=None,
                     help="updates per chain per launch (1000; tempering: 200)")
     ap.add_argument("--report-every", type=int, default=100,
@@ -203,6 +206,10 @@ def main():
     problem = synthetic.make_problem(T=args.timesteps, n_landmarks=args.landmarks, k_nearest=args.k_nearest,
                                      seed=args.seed, max_tries=2 if tempering else 8,
                                      bearing_stddev=args.bearing_stddev if bearing else None)
+    if args.total_chains:
+        if args.total_chains % world:
+            raise SystemExit("--total-chains must be a multiple of the number of GPUs")
+        args.chains = args.total_chains // world
     T, F, N, C = problem["T"], problem["F"], problem["N"], args.chains
     # one explicit stream for the library's kernels, torch's reductions and the collectives:
     # a zero stream handle would make the library create a private stream of its own
@@ -316,7 +323,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed_max / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.total_chains else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
