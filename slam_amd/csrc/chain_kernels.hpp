@@ -68,7 +68,7 @@ struct Dev {
   const double* obisd;        // [Ncap] 1 / that
   double ubsig_inv;           // 1/sigma of the bearings when they all have the same sigma, else 0
   // ---- chains --------------------------------------------------------------
-  uint32_t C, NTcap;
+  uint32_t C;
   double *relx, *rely, *relth;  // [C][Tcap]   relative pose of state edge t
   PoseXY* pxy;                  // [C][Tcap+1] world translation of pose k
   double* pth;                  // [C][Tcap+1] its (unwrapped) angle
@@ -122,7 +122,6 @@ struct ChainCtl {
 constexpr int kMaxSeg = 256;   // landmark segments evaluated per pass
 constexpr int kActCap = 1024;  // landmarks examined per round (blockDim.x divides it)
 constexpr int kMaxWaves = 16;
-constexpr int kTileShift = 8;  // poses per tile of the rebuild scan = 256
 constexpr uint32_t kMaxRetry = 1u << 16;
 
 // Slices a chain's stream of `total` readings is cut into in split mode: as many as the launch
@@ -1763,64 +1762,78 @@ __global__ void commit_kernel(Dev d, uint32_t c, int kind, uint32_t idx, double 
   }
 }
 
-// ---- cumulative pose rebuild: three-pass SE(2) scan ---------------------------
-// pass 1: grid = (tiles, chains), block = 256.  Lane j of tile b composes
-// rel[256 b .. 256 b + j] and leaves it, still tile-local, in pose slot
-// 256 b + j + 1; the tile total goes to `tot`.
-__global__ void scan_tiles_kernel(Dev d, uint32_t Tcur, Pose* tot) {
-  __shared__ Pose stage[kMaxWaves];
-  const uint32_t c = blockIdx.y, b = blockIdx.x, j = threadIdx.x;
-  const uint32_t k = (b << kTileShift) + j;
-  const size_t rbase = size_t(c) * d.Tcap, pbase = size_t(c) * (d.Tcap + 1);
-  Pose v = pose_identity();
-  if (k < Tcur) v = Pose{d.relx[rbase + k], d.rely[rbase + k], d.relth[rbase + k]};
-  Pose total;
-  const Pose inc = block_scan_inclusive(v, PoseOp{}, stage, total);
-  if (k < Tcur) {
-    d.pxy[pbase + k + 1] = PoseXY{inc.x, inc.y};
-    d.pth[pbase + k + 1] = inc.th;
+// ---- cumulative pose rebuild: SE(2) scan ---------------------------------------
+// P[k+1] = rel[0] o rel[1] o ... o rel[k] for every chain (P[0] = identity).  A chain is cut into
+// `nseg` segments of `seg_len` relative poses, one workgroup each (grid = (nseg, chains)), which
+// walks its segment tile by tile with the running composition in registers (chained_scan).  With
+// many chains nseg = 1: one kernel, every pose read once and written once.  With few chains
+// (a handful of replicas on a long trajectory) a first pass (WRITE = false) leaves only each
+// segment's total in `tot`, scan_offsets_kernel turns the totals into the world pose at each
+// segment's start, and the second pass (WRITE = true) starts from there.
+struct ScanArgs {
+  const double *relx, *rely, *relth;  // [chains][rstride] relative pose of edge k
+  PoseXY* pxy;                        // [chains][pstride] slot k + 1 = world translation after edge k
+  double* pth;                        // [chains][pstride] its unwrapped angle
+  uint32_t rstride, pstride;
+  uint32_t n;        // relative poses per chain
+  uint32_t nseg;     // segments per chain
+  uint32_t seg_len;  // relative poses per segment, a multiple of the tile
+  Pose* tot;         // [chains][nseg] segment totals / offsets; unused when nseg == 1
+};
+constexpr int kScanLanes = 256, kScanPerLane = 4;          // tile = 1024 poses
+constexpr uint32_t kScanTargetGroups = 1024;               // workgroups a rebuild should offer the GPU
+constexpr uint32_t kScanMinSegmentTiles = 4;               // no segment shorter than this many tiles
+
+template <bool WRITE>
+__global__ void __launch_bounds__(kScanLanes) scan_chain_kernel(ScanArgs a) {
+  __shared__ PoseCS stage[2][kScanMaxWaves];
+  const uint32_t seg = blockIdx.x, c = blockIdx.y;
+  const uint32_t lo = seg * a.seg_len;
+  const uint32_t hi = a.n - lo < a.seg_len ? a.n : lo + a.seg_len;  // lo <= n by construction of the plan
+  const double* __restrict__ rx = a.relx + size_t(c) * a.rstride;
+  const double* __restrict__ ry = a.rely + size_t(c) * a.rstride;
+  const double* __restrict__ rth = a.relth + size_t(c) * a.rstride;
+  PoseXY* __restrict__ pxy = a.pxy + size_t(c) * a.pstride;
+  double* __restrict__ pth = a.pth + size_t(c) * a.pstride;
+  const PoseCSOp op;
+  PoseCS carry = op.identity();
+  if (WRITE && a.nseg > 1) carry = op.lift(a.tot[size_t(c) * a.nseg + seg]);
+  if (WRITE && seg == 0 && threadIdx.x == 0) {
+    pxy[0] = PoseXY{0.0, 0.0};
+    pth[0] = 0.0;
   }
-  if (j == 0) tot[size_t(c) * d.NTcap + b] = total;
+  carry = chained_scan<kScanPerLane>(
+      op, lo, hi, carry, [&](uint32_t i) { return Pose{rx[i], ry[i], rth[i]}; },
+      [&](uint32_t i, const PoseCS& v) {
+        if (WRITE) {
+          pxy[i + 1] = PoseXY{v.x, v.y};
+          pth[i + 1] = v.th;
+        }
+      },
+      stage);
+  if (!WRITE && threadIdx.x == 0) a.tot[size_t(c) * a.nseg + seg] = Pose{carry.x, carry.y, carry.th};
 }
 
-// pass 2: grid = chains.  Exclusive scan of the tile totals, in place: tot[b]
-// becomes the world pose at the start of tile b.
-__global__ void scan_offsets_kernel(Dev d, uint32_t ntiles, Pose* tot) {
+// grid = chains.  Exclusive scan of a chain's segment totals, in place: tot[s] becomes the world
+// pose at the start of segment s.
+__global__ void scan_offsets_kernel(uint32_t nseg, Pose* tot) {
   __shared__ Pose stage[kMaxWaves];
   __shared__ Pose incl[256];
-  const uint32_t c = blockIdx.x;
-  Pose* t = tot + size_t(c) * d.NTcap;
+  Pose* t = tot + size_t(blockIdx.x) * nseg;
   Pose carry = pose_identity();
-  for (uint32_t b0 = 0; b0 < ntiles; b0 += blockDim.x) {
+  for (uint32_t b0 = 0; b0 < nseg; b0 += blockDim.x) {
     const uint32_t b = b0 + threadIdx.x;
     Pose v = pose_identity();
-    if (b < ntiles) v = t[b];
+    if (b < nseg) v = t[b];
     Pose total;
     incl[threadIdx.x] = block_scan_inclusive(v, PoseOp{}, stage, total);
     __syncthreads();
     // exclusive value of lane j = carry o inclusive value of lane j-1
     const Pose excl = threadIdx.x == 0 ? carry : compose(carry, incl[threadIdx.x - 1]);
     __syncthreads();
-    if (b < ntiles) t[b] = excl;
+    if (b < nseg) t[b] = excl;
     carry = compose(carry, total);
   }
-}
-
-// pass 3: grid = (tiles, chains), block = 256.  P[k] = offset[tile] o local[k].
-__global__ void scan_apply_kernel(Dev d, uint32_t Tcur, const Pose* tot) {
-  const uint32_t c = blockIdx.y, b = blockIdx.x;
-  const uint32_t k = (b << kTileShift) + threadIdx.x;  // relative-pose index; pose slot k + 1
-  const size_t pbase = size_t(c) * (d.Tcap + 1);
-  if (b == 0 && threadIdx.x == 0) {
-    d.pxy[pbase] = PoseXY{0.0, 0.0};
-    d.pth[pbase] = 0.0;
-  }
-  if (k >= Tcur || b == 0) return;  // tile 0 is already in world coordinates
-  const Pose off = tot[size_t(c) * d.NTcap + b];
-  const PoseXY l = d.pxy[pbase + k + 1];
-  const Pose w = compose(off, Pose{l.x, l.y, d.pth[pbase + k + 1]});
-  d.pxy[pbase + k + 1] = PoseXY{w.x, w.y};
-  d.pth[pbase + k + 1] = w.th;
 }
 
 // World landmark positions and plain edge weights of one chain.
@@ -2152,25 +2165,19 @@ __global__ void features_from_world_kernel(Dev d, uint32_t first, uint32_t F, co
   d.fey[fi] = e.y;
 }
 
-// Scan self-test over the integer affine group (exact).
-__global__ void scan_affine_kernel(uint32_t n, int32_t p, const int32_t* a, const int32_t* b, int32_t* oa,
-                                   int32_t* ob) {
-  __shared__ Affine stage[kMaxWaves];
+// Scan self-test over the integer affine group (exact): the chained scan that builds the pose
+// tables, one workgroup, on the group of the reference's own tree test.
+__global__ void __launch_bounds__(kScanLanes) scan_affine_kernel(uint32_t n, int32_t p, const int32_t* a,
+                                                                  const int32_t* b, int32_t* oa, int32_t* ob) {
+  __shared__ Affine stage[2][kScanMaxWaves];
   const AffineOp op{p};
-  Affine carry = op.identity();
-  for (uint32_t i0 = 0; i0 < n; i0 += blockDim.x) {
-    const uint32_t i = i0 + threadIdx.x;
-    Affine v = op.identity();
-    if (i < n) v = Affine{a[i], b[i]};
-    Affine total;
-    Affine inc = block_scan_inclusive(v, op, stage, total);
-    inc = op(carry, inc);
-    if (i < n) {
-      oa[i] = inc.a;
-      ob[i] = inc.b;
-    }
-    carry = op(carry, total);
-  }
+  chained_scan<kScanPerLane>(
+      op, 0u, n, op.identity(), [&](uint32_t i) { return Affine{a[i], b[i]}; },
+      [&](uint32_t i, const Affine& v) {
+        oa[i] = v.a;
+        ob[i] = v.b;
+      },
+      stage);
 }
 
 }  // namespace mg

@@ -32,7 +32,7 @@ struct mcmcgpu_ctx {
   bool own_stream = false;
   Dev d{};
   std::vector<void*> allocations;
-  Pose* scan_tot = nullptr;  // [C][NTcap] tile totals / offsets of the rebuild scan
+  Pose* scan_tot = nullptr;  // [scan_total_slots(C)] segment totals / offsets of the rebuild scan
   uint32_t* seed_stage = nullptr;  // [C]
   double* scratch = nullptr;  // readout staging: max(3*(Tcap+1), ...) doubles
   size_t scratch_doubles = 0;
@@ -287,14 +287,56 @@ int lay_out(mcmcgpu_handle h, bool with_slack) {
   return 0;
 }
 
-int rebuild_impl(mcmcgpu_handle h) {
+// How a rebuild of `chains` pose tables of n relative poses each is cut into workgroups: whole
+// chains when there are enough of them to fill the GPU, otherwise segments of at least
+// kScanMinSegmentTiles tiles.  A function of (chains, n) only, so that two rebuilds of the same
+// data compose in the same order.
+struct ScanPlan {
+  uint32_t nseg, seg_len;
+};
+ScanPlan scan_plan(uint32_t chains, uint32_t n) {
+  const uint32_t tile = uint32_t(kScanLanes) * kScanPerLane;
+  const uint32_t want = chains >= kScanTargetGroups ? 1 : (kScanTargetGroups + chains - 1) / std::max<uint32_t>(chains, 1);
+  const uint32_t longest = std::max<uint32_t>(1, n / (kScanMinSegmentTiles * tile));
+  uint32_t nseg = std::min(want, longest);
+  const uint32_t per = (n + nseg - 1) / nseg;
+  const uint32_t seg_len = std::max<uint32_t>(tile, (per + tile - 1) / tile * tile);
+  nseg = std::max<uint32_t>(1, (n + seg_len - 1) / seg_len);  // no empty segment at the end
+  return ScanPlan{nseg, seg_len};
+}
+// Segment totals a rebuild of `chains` chains can need: chains * nseg < kScanTargetGroups + chains.
+size_t scan_total_slots(size_t chains) { return kScanTargetGroups + chains; }
+
+// The scan's launches on `stream`; `tot` must hold chains * plan.nseg poses when plan.nseg > 1.
+hipError_t launch_scan(hipStream_t stream, ScanArgs a, uint32_t chains) {
+  if (chains == 0) return hipSuccess;
+  const dim3 grid(a.nseg, chains), lanes(kScanLanes);
+  if (a.nseg > 1) {
+    hipLaunchKernelGGL(scan_chain_kernel<false>, grid, lanes, 0, stream, a);
+    hipLaunchKernelGGL(scan_offsets_kernel, dim3(chains), dim3(256), 0, stream, a.nseg, a.tot);
+  }
+  hipLaunchKernelGGL(scan_chain_kernel<true>, grid, lanes, 0, stream, a);
+  return hipGetLastError();
+}
+
+// Cumulative poses of chains [first, first + count) from their relative poses.
+int rebuild_impl(mcmcgpu_handle h, uint32_t first, uint32_t count) {
+  const Dev& d = h->d;
   const uint32_t Tcur = edges_grown(h);
-  const uint32_t ntiles = std::max<uint32_t>(1, (Tcur + (1u << kTileShift) - 1) >> kTileShift);
-  const dim3 tiles(ntiles, h->chains), lanes(1u << kTileShift);
-  hipLaunchKernelGGL(scan_tiles_kernel, tiles, lanes, 0, h->stream, h->d, Tcur, h->scan_tot);
-  hipLaunchKernelGGL(scan_offsets_kernel, dim3(h->chains), dim3(256), 0, h->stream, h->d, ntiles, h->scan_tot);
-  hipLaunchKernelGGL(scan_apply_kernel, tiles, lanes, 0, h->stream, h->d, Tcur, h->scan_tot);
-  HIP_TRY(h, hipGetLastError());
+  const ScanPlan plan = scan_plan(count, Tcur);
+  ScanArgs a{};
+  a.relx = d.relx + size_t(first) * d.Tcap;
+  a.rely = d.rely + size_t(first) * d.Tcap;
+  a.relth = d.relth + size_t(first) * d.Tcap;
+  a.pxy = d.pxy + size_t(first) * (d.Tcap + 1);
+  a.pth = d.pth + size_t(first) * (d.Tcap + 1);
+  a.rstride = d.Tcap;
+  a.pstride = d.Tcap + 1;
+  a.n = Tcur;
+  a.nseg = plan.nseg;
+  a.seg_len = plan.seg_len;
+  a.tot = h->scan_tot;
+  HIP_TRY(h, launch_scan(h->stream, a, count));
   return 0;
 }
 
@@ -340,7 +382,6 @@ int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out) {
   d.Fcap = std::max<uint32_t>(cfg->max_features, 1);
   d.Ncap = uint32_t(slots);
   d.C = 0;
-  d.NTcap = (d.Tcap >> kTileShift) + 1;
   d.uniform_first = cfg->feature_uniform_first ? 1 : 0;
   d.trace_cap = cfg->trace_capacity;
   const size_t C = cfg->max_chains;
@@ -399,7 +440,7 @@ int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out) {
   ALLOC(h->exch_u, C / 2 + 1);
   ALLOC(h->exch_counts, 2);
   if (d.trace_cap) ALLOC(d.trace, C * d.trace_cap);
-  ALLOC(h->scan_tot, C * d.NTcap);
+  ALLOC(h->scan_tot, scan_total_slots(C));
   ALLOC(h->seed_stage, C);
   ALLOC(h->reports, size_t(kMaxOwnReports) * C);
   d.max_slices = cfg->max_split_slices;
@@ -959,7 +1000,7 @@ int mcmcgpu_rebuild(mcmcgpu_handle h) {
   if (!h) return MCMCGPU_ERR_ARGUMENT;
   if (h->chains == 0) return fail(h, MCMCGPU_ERR_STATE, "no chains");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
-  return rebuild_impl(h);
+  return rebuild_impl(h, 0, h->chains);
 }
 
 int mcmcgpu_get_log_likelihood(mcmcgpu_handle h, double* out) {
@@ -1266,7 +1307,7 @@ int mcmcgpu_import_state(mcmcgpu_handle h, uint32_t chain, const void* dev_in, d
   HIP_TRY(h, cp(d.fey + size_t(chain) * d.Fcap, in + 3 * T + F, F));
   HIP_TRY(h, hipMemcpyAsync(d.ll + chain, &log_likelihood, sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
-  if (int rc = rebuild_impl(h)) return rc;
+  if (int rc = rebuild_impl(h, chain, 1)) return rc;
   hipLaunchKernelGGL(reweigh_kernel, dim3(1), dim3(256), 0, h->stream, d, chain, uint32_t(T));
   // the control part of the log likelihood (kept apart for tempering) from scratch; the total stays
   // the exporter's figure (the from-scratch total lands in the idle tile-total buffer of the scan)
@@ -1311,7 +1352,7 @@ int mcmcgpu_load_state(mcmcgpu_handle h, uint32_t first, uint32_t count, const d
   hipLaunchKernelGGL(load_state_kernel, dim3(count), dim3(256), 0, h->stream, d, first, T, F, drel, dmeta);
   HIP_TRY(h, hipGetLastError());
   h->next_timestep = T + 1;
-  if (int rc = rebuild_impl(h)) return rc;
+  if (int rc = rebuild_impl(h, first, count)) return rc;
   if (F) {
     hipLaunchKernelGGL(features_from_world_kernel, dim3((F + 255) / 256, count), dim3(256), 0, h->stream, d, first, F,
                        dworld);
@@ -1387,7 +1428,7 @@ int mcmcgpu_selftest_scan(int32_t device, uint32_t n, int32_t p, const int32_t* 
   hipError_t e = hipMemcpy(da, a, sizeof(int32_t) * n, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(db, b, sizeof(int32_t) * n, hipMemcpyHostToDevice);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(scan_affine_kernel, dim3(1), dim3(256), 0, nullptr, n, p, da, db, oa, ob);
+    hipLaunchKernelGGL(scan_affine_kernel, dim3(1), dim3(kScanLanes), 0, nullptr, n, p, da, db, oa, ob);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpy(out_a, oa, sizeof(int32_t) * n, hipMemcpyDeviceToHost);

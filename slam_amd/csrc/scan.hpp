@@ -1,8 +1,14 @@
-// Wavefront-level inclusive prefix scan over an arbitrary associative,
-// NON-commutative operation (gfx950: 64-lane wavefronts).  Used to build the
-// cumulative SE(2) poses of a chain from its relative poses: Kogge-Stone steps
-// with lane shuffles inside a wavefront, wavefront totals staged through LDS,
-// carries across workgroup-sized tiles applied on the left.
+// Inclusive prefix scan over an arbitrary associative, NON-commutative
+// operation for gfx950 (64-lane wavefronts).  Used to build the cumulative SE(2)
+// poses of a chain from its relative poses.
+//
+// Shape: one workgroup walks a run of elements tile by tile and carries the
+// composition of everything before the tile in registers (chained_scan).  Inside
+// a tile every lane owns K consecutive elements: it composes them, the lane
+// totals are scanned across the wavefront with lane shuffles (Kogge-Stone), the
+// wavefront totals go through LDS, and the lane then composes its K elements
+// once more onto its exclusive prefix and stores them.  Every element is read
+// once and written once.
 //
 // The scan replaces the reference's Fenwick tree of poses
 // (src/utility/bitree.hpp:155-321): prefix(k) below equals
@@ -16,13 +22,45 @@
 
 namespace mg {
 
+constexpr int kScanMaxWaves = 16;
+
 MG_DEV Pose shfl_up_any(const Pose& v, int d) {
   return Pose{__shfl_up(v.x, d), __shfl_up(v.y, d), __shfl_up(v.th, d)};
 }
 
 struct PoseOp {
+  using value_type = Pose;
+  using raw_type = Pose;
   MG_DEV Pose identity() const { return pose_identity(); }
+  MG_DEV Pose lift(const Pose& r) const { return r; }
   MG_DEV Pose operator()(const Pose& a, const Pose& b) const { return compose(a, b); }
+};
+
+// A pose that carries the cosine and sine of its angle, so that composing two of them is a
+// handful of fused multiply-adds instead of a sincos: the scan takes ONE sincos per input pose
+// (lift) and none afterwards.  The angle itself stays the plain, unwrapped sum the reference
+// keeps (src/planar_robot/pose.hpp:67-71); (c, s) are products of rotations and differ from
+// cos/sin of that sum by a few ulp per composition level.
+struct PoseCS {
+  double x, y, c, s, th;
+};
+MG_DEV PoseCS shfl_up_any(const PoseCS& v, int d) {
+  return PoseCS{__shfl_up(v.x, d), __shfl_up(v.y, d), __shfl_up(v.c, d), __shfl_up(v.s, d), __shfl_up(v.th, d)};
+}
+struct PoseCSOp {
+  using value_type = PoseCS;
+  using raw_type = Pose;
+  MG_DEV PoseCS identity() const { return PoseCS{0.0, 0.0, 1.0, 0.0, 0.0}; }
+  MG_DEV PoseCS lift(const Pose& r) const {
+    double s, c;
+    sincos(r.th, &s, &c);
+    return PoseCS{r.x, r.y, c, s, r.th};
+  }
+  // a then b:  t = a.t + R(a) b.t,  R = R(a) R(b),  th = a.th + b.th
+  MG_DEV PoseCS operator()(const PoseCS& a, const PoseCS& b) const {
+    return PoseCS{fma(a.c, b.x, fma(-a.s, b.y, a.x)), fma(a.s, b.x, fma(a.c, b.y, a.y)), fma(a.c, b.c, -(a.s * b.s)),
+                  fma(a.s, b.c, a.c * b.s), a.th + b.th};
+  }
 };
 
 // x -> a + b*x (mod p); (f.g)(x) = f(g(x))  <=>  (a,b)+(c,d) = (a + b*c, b*d)
@@ -31,8 +69,11 @@ struct Affine {
 };
 MG_DEV Affine shfl_up_any(const Affine& v, int d) { return Affine{__shfl_up(v.a, d), __shfl_up(v.b, d)}; }
 struct AffineOp {
+  using value_type = Affine;
+  using raw_type = Affine;
   int32_t p;
   MG_DEV Affine identity() const { return Affine{0, 1}; }
+  MG_DEV Affine lift(const Affine& r) const { return r; }
   MG_DEV Affine operator()(const Affine& f, const Affine& g) const {
     const long long a = (long long)f.a + (long long)f.b * g.a;
     const long long b = (long long)f.b * g.b;
@@ -74,6 +115,65 @@ MG_DEV T block_scan_inclusive(T v, const Op& op, T* stage, T& total) {
   if (wave > 0) v = op(before, v);
   __syncthreads();
   return v;
+}
+
+// Elements [lo, hi) scanned by ONE workgroup, tile by tile (a tile = blockDim.x * K elements),
+// `carry` = the composition of everything before `lo`.  load(i) fetches element i in its stored
+// form, op.lift turns it into the scanned type, store(i, v) receives carry o e[lo] o ... o e[i].
+// Returns carry o e[lo] o ... o e[hi-1] in every thread.  The raw elements of the next tile are
+// requested before the current one is composed, so their latency hides behind the arithmetic.
+// `stage` is LDS room for 2 x kScanMaxWaves values (two tiles alternate, one barrier per tile).
+// All threads of the workgroup must call it with the same lo, hi and carry.
+template <int K, class Op, class Load, class Store>
+MG_DEV typename Op::value_type chained_scan(const Op& op, uint32_t lo, uint32_t hi, typename Op::value_type carry,
+                                            Load load, Store store, typename Op::value_type (*stage)[kScanMaxWaves]) {
+  using T = typename Op::value_type;
+  using Raw = typename Op::raw_type;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const uint32_t tile = blockDim.x * K;
+  Raw next[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const uint32_t i = lo + threadIdx.x * K + k;
+    next[k] = Raw{};
+    if (i < hi) next[k] = load(i);
+  }
+  int buf = 0;
+  for (uint32_t base = lo; base < hi; base += tile, buf ^= 1) {
+    const uint32_t first = base + threadIdx.x * K;
+    Raw raw[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) raw[k] = next[k];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const uint32_t i = first + tile + k;
+      if (i < hi) next[k] = load(i);
+    }
+    T v[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = first + k < hi ? op.lift(raw[k]) : op.identity();
+    T mine = v[0];
+#pragma unroll
+    for (int k = 1; k < K; ++k) mine = op(mine, v[k]);
+    const T inc = wave_scan_inclusive(mine, op);
+    if (lane == 63) stage[buf][wave] = inc;
+    T excl = shfl_up_any(inc, 1);
+    if (lane == 0) excl = op.identity();
+    __syncthreads();
+    T before = carry, all = carry;
+    for (int w = 0; w < nwaves; ++w) {
+      if (w == wave) before = all;
+      all = op(all, stage[buf][w]);
+    }
+    carry = all;
+    T acc = op(before, excl);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      acc = op(acc, v[k]);
+      if (first + k < hi) store(first + k, acc);
+    }
+  }
+  return carry;
 }
 
 }  // namespace mg

@@ -209,8 +209,32 @@ def test_rebuild_scan_matches_oracle_accumulate():
     g.grow(p["T"])
     grown = g.get_state(0)["cum"].copy()
     g.rebuild()
-    assert_close(g.get_state(0)["cum"], w.state(0)["cum"], REL, "three-pass scan vs bitree accumulate")
-    assert_close(g.get_state(0)["cum"], grown, 1e-11, "three-pass scan vs poses appended one by one")
+    assert_close(g.get_state(0)["cum"], w.state(0)["cum"], REL, "scan vs bitree accumulate")
+    assert_close(g.get_state(0)["cum"], grown, 1e-11, "scan vs poses appended one by one")
+
+
+@pytest.mark.parametrize("T,chains", [(20000, 2), (9000, 3), (5000, 1)])
+def test_rebuild_scan_in_segments_matches_oracle_accumulate(T, chains):
+    """Few chains on a long trajectory: the rebuild cuts every chain into segments (one workgroup each, totals,
+    offsets, second pass); against bitree<pose>::accumulate of the oracle, every chain its own trajectory."""
+    p = synthetic.make_problem(T=T, n_landmarks=12, k_nearest=3, seed=T, lap_steps=400, wobble_period=900,
+                               range_stddev=1.0, landmark_spread=8.0)
+    seeds = capi.seed_sequence(T, chains)
+    rng = np.random.default_rng(T)
+    w = oracle_lib.World()
+    w.set_input(p["ctrl_mean"], p["ctrl_std"], p["obs_t"], p["obs_f"], p["obs_mean"], p["obs_std"])
+    w.replay(p["T"])
+    g = gpu_handle(p, seeds, trace_capacity=0)
+    g.load_state(p["true_rel"], p["landmarks"])
+    for c in range(chains):
+        rel = p["true_rel"] + rng.normal(0.0, [1e-3, 1e-3, 1e-4], size=p["true_rel"].shape)
+        k = w.add_detached_chain(int(seeds[c]))
+        w.load_state(k, rel, np.arange(p["F"]), p["landmarks"])
+        g.load_state(rel, p["landmarks"], first=c, count=1)
+    g.rebuild()
+    g.sync()
+    for c in range(chains):
+        assert_close(g.get_state(c)["cum"], w.state(c)["cum"], REL, f"chain {c}: segmented scan vs bitree accumulate")
 
 
 @pytest.mark.parametrize("threads", [64, 128, 512, 1024])
