@@ -229,6 +229,25 @@ int mcmcgpu_commit(mcmcgpu_handle h, uint32_t chain, int kind, uint32_t index, c
  * src/utility/bitree.hpp:182-184); removes accumulated rounding drift. */
 int mcmcgpu_rebuild(mcmcgpu_handle h);
 
+/* The scan of mcmcgpu_rebuild for callers that cannot allocate.  NO counterpart in the reference
+ * and no handle: it exists for code that must not call hipMalloc or have a library do it -- work
+ * under HIP graph capture, tight serving loops, harnesses that forbid allocation.  The caller
+ * passes inputs and outputs as DEVICE pointers: relative poses of `chains` trajectories of n
+ * edges each, component arrays [chains][rel_stride]; out come the cumulative poses, translation
+ * dev_cum_xy [chains][cum_stride] as (x, y) pairs (16-byte aligned) and unwrapped angle dev_cum_th
+ * [chains][cum_stride], slot k = the pose after k edges (slot 0 = identity), exactly the numbers
+ * mcmcgpu_rebuild leaves in a handle's pose tables for the same chains and relative poses.  The
+ * segment totals the scan needs when few chains are cut into many workgroups live in a static
+ * device array of the library (122 880 bytes per GPU, held until the process ends) instead of
+ * allocated memory; the call allocates and frees nothing and runs on `stream` (NULL = the null
+ * stream) of `device`.  Limits: chains <= 4096 (MCMCGPU_ERR_CAPACITY beyond), n < 2^32 - 1,
+ * rel_stride >= n, cum_stride >= n + 1.  All calls on one GPU share that array: calls that may
+ * overlap on one GPU (different streams or threads) race and must be serialised by the caller.
+ * Errors are reported through mcmcgpu_last_error(NULL). */
+int mcmcgpu_scan_poses_static(int32_t device, void* stream, uint32_t chains, uint32_t n, const double* dev_rel_x,
+                              const double* dev_rel_y, const double* dev_rel_th, uint32_t rel_stride,
+                              double* dev_cum_xy, double* dev_cum_th, uint32_t cum_stride);
+
 /* get_log_likelihood (mcmc_slam.hpp:173) for chains [0, C). */
 int mcmcgpu_get_log_likelihood(mcmcgpu_handle h, double* out);
 /* slam_log_likelihood (src/slam/slam_likelihood.hpp:26-58) recomputed from

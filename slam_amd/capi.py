@@ -70,6 +70,7 @@ EXPORTS = [
     "mcmcgpu_eval_llr",
     "mcmcgpu_commit",
     "mcmcgpu_rebuild",
+    "mcmcgpu_scan_poses_static",
     "mcmcgpu_get_log_likelihood",
     "mcmcgpu_full_log_likelihood",
     "mcmcgpu_get_state",
@@ -154,6 +155,20 @@ def selftest_scan(a, b, p, device=0):
     if rc != 0:
         raise RuntimeError(f"mcmcgpu_selftest_scan failed ({rc}): {lib.mcmcgpu_last_error(None).decode()}")
     return oa, ob
+
+
+def scan_poses_static(chains, n, rel_x_ptr, rel_y_ptr, rel_th_ptr, rel_stride, cum_xy_ptr, cum_th_ptr, cum_stride,
+                      device=0, stream=None):
+    """mcmcgpu_scan_poses_static: cumulative poses from relative poses, device pointers in and out,
+    nothing allocated (the scan's partial results live in a static device array of the library)."""
+    lib = load_library()
+    rc = lib.mcmcgpu_scan_poses_static(ctypes.c_int32(device), ctypes.c_void_p(stream), ctypes.c_uint32(chains),
+                                       ctypes.c_uint32(n), ctypes.c_void_p(rel_x_ptr), ctypes.c_void_p(rel_y_ptr),
+                                       ctypes.c_void_p(rel_th_ptr), ctypes.c_uint32(rel_stride),
+                                       ctypes.c_void_p(cum_xy_ptr), ctypes.c_void_p(cum_th_ptr),
+                                       ctypes.c_uint32(cum_stride))
+    if rc != 0:
+        raise RuntimeError(f"mcmcgpu_scan_poses_static failed ({rc}): {lib.mcmcgpu_last_error(None).decode()}")
 
 
 class McmcGpu:

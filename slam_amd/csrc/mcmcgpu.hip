@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -287,6 +288,35 @@ int lay_out(mcmcgpu_handle h, bool with_slack) {
   return 0;
 }
 
+// ---- scratch that no call allocates -------------------------------------------------------------
+// mcmcgpu_scan_poses_static keeps the segment totals of its scan here instead of in memory a
+// handle owns.  Every GPU the library runs on holds its own copy of this array, at its own
+// address, until the process ends; in host code the array's NAME is only a stand-in for it, so
+// the address is asked for once per device (static_scratch_on) and only that pointer is ever
+// handed to a kernel.  All calls on one GPU share the array: calls that overlap there race.
+constexpr uint32_t kStaticScanChains = 4096;  // most chains one mcmcgpu_scan_poses_static call takes
+constexpr size_t kStaticScratchBytes = (size_t(kScanTargetGroups) + kStaticScanChains) * sizeof(Pose);  // 122 880
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+constexpr int kMaxDevices = 64;
+std::mutex g_static_scratch_mutex;
+void* g_static_scratch[kMaxDevices] = {};
+
+// Device address of `scratch` on `device`, which must be the current device.
+hipError_t static_scratch_on(int device, void** out) {
+  if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> lock(g_static_scratch_mutex);
+  if (!g_static_scratch[device]) {
+    void* p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!p) return hipErrorInvalidSymbol;
+    g_static_scratch[device] = p;
+  }
+  *out = g_static_scratch[device];
+  return hipSuccess;
+}
+
 // How a rebuild of `chains` pose tables of n relative poses each is cut into workgroups: whole
 // chains when there are enough of them to fill the GPU, otherwise segments of at least
 // kScanMinSegmentTiles tiles.  A function of (chains, n) only, so that two rebuilds of the same
@@ -363,6 +393,12 @@ int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out) {
   if (slots > 0xFFFFFFFFull) return fail(nullptr, MCMCGPU_ERR_CAPACITY, "max_observations too large");
   hipError_t e = hipSetDevice(cfg->device);
   if (e != hipSuccess) return fail(nullptr, MCMCGPU_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  {  // the library's set-up call on this device: where mcmcgpu_scan_poses_static's scratch lives here
+    void* unused = nullptr;
+    e = static_scratch_on(cfg->device, &unused);
+    if (e != hipSuccess)
+      return fail(nullptr, MCMCGPU_ERR_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+  }
 
   mcmcgpu_handle h = new mcmcgpu_ctx();
   h->cfg = *cfg;
@@ -1001,6 +1037,45 @@ int mcmcgpu_rebuild(mcmcgpu_handle h) {
   if (h->chains == 0) return fail(h, MCMCGPU_ERR_STATE, "no chains");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   return rebuild_impl(h, 0, h->chains);
+}
+
+int mcmcgpu_scan_poses_static(int32_t device, void* stream, uint32_t chains, uint32_t n, const double* dev_rel_x,
+                              const double* dev_rel_y, const double* dev_rel_th, uint32_t rel_stride,
+                              double* dev_cum_xy, double* dev_cum_th, uint32_t cum_stride) {
+  if (!dev_rel_x || !dev_rel_y || !dev_rel_th || !dev_cum_xy || !dev_cum_th)
+    return fail(nullptr, MCMCGPU_ERR_ARGUMENT, "null argument");
+  if (chains == 0) return fail(nullptr, MCMCGPU_ERR_ARGUMENT, "chains must be positive");
+  if (chains > kStaticScanChains)
+    return fail(nullptr, MCMCGPU_ERR_CAPACITY, "mcmcgpu_scan_poses_static takes at most " +
+                                                   std::to_string(kStaticScanChains) + " chains per call");
+  if (n == 0xFFFFFFFFu || rel_stride < n || cum_stride < n + 1)
+    return fail(nullptr, MCMCGPU_ERR_ARGUMENT, "strides shorter than the trajectory");
+  if (reinterpret_cast<uintptr_t>(dev_cum_xy) % 16 != 0)
+    return fail(nullptr, MCMCGPU_ERR_ARGUMENT, "dev_cum_xy must be 16-byte aligned");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+    return fail(nullptr, MCMCGPU_ERR_HIP, "no such HIP device (this library has no CPU path)");
+  mcmcgpu_handle h = nullptr;
+  HIP_TRY(h, hipSetDevice(device));
+  void* tot = nullptr;
+  HIP_TRY(h, static_scratch_on(device, &tot));
+  const ScanPlan plan = scan_plan(chains, n);
+  if (size_t(chains) * plan.nseg * sizeof(Pose) > kStaticScratchBytes)  // cannot happen for chains <= kStaticScanChains
+    return fail(nullptr, MCMCGPU_ERR_CAPACITY, "scan plan exceeds the static scratch");
+  ScanArgs a{};
+  a.relx = dev_rel_x;
+  a.rely = dev_rel_y;
+  a.relth = dev_rel_th;
+  a.pxy = reinterpret_cast<PoseXY*>(dev_cum_xy);
+  a.pth = dev_cum_th;
+  a.rstride = rel_stride;
+  a.pstride = cum_stride;
+  a.n = n;
+  a.nseg = plan.nseg;
+  a.seg_len = plan.seg_len;
+  a.tot = static_cast<Pose*>(tot);  // every slot the second pass reads is written by the first: nothing to clear
+  HIP_TRY(h, launch_scan(static_cast<hipStream_t>(stream), a, chains));
+  return 0;
 }
 
 int mcmcgpu_get_log_likelihood(mcmcgpu_handle h, double* out) {
