@@ -449,6 +449,26 @@ void ora_world_average(void* p, double* accumulated, double* features) {
 // n successive 32-bit engine draws from random_source(seed): the chain seeds
 // of multi_mcmc (src/slam/multi_mcmc.hpp:160-166) and the module seeds of
 // src/main.cpp:133-147.
+// The six columns of the controls.txt that the reference's loader writes (src/dataset.cpp:96-109),
+// recomputed from the logs under dir/name: rows[t][6].  Returns the number of rows, or -1; with
+// rows == NULL only counts.  Pins loader, bitree<pose>, pose arithmetic, observe and wrap_angle
+// against the copies of that file the reference ships.
+int ora_plaza_controls_rows(const char* dir, const char* name, double* rows, std::uint32_t capacity) {
+  try {
+    oracle::ground_truth truth;
+    const oracle::dataset d = oracle::read_range_only_data(dir, name, &truth);
+    const auto r = oracle::controls_txt_rows(d, truth);
+    if (rows) {
+      if (r.size() > capacity) return -1;
+      for (std::size_t t = 0; t < r.size(); ++t)
+        for (int k = 0; k < 6; ++k) rows[6 * t + k] = r[t][k];
+    }
+    return int(r.size());
+  } catch (const std::exception&) {
+    return -1;
+  }
+}
+
 void ora_seed_sequence(std::uint32_t seed, std::uint32_t n, std::uint32_t* out) {
   random_source r(seed);
   for (std::uint32_t i = 0; i < n; ++i) out[i] = r();

@@ -6,12 +6,19 @@
 // call this file; it exists so that tests and the benchmark's cpu_baseline leg
 // have an independent statement of the reference algorithm to compare with.
 //
-// Parity status: the generic tree (`bitree`) is pinned by the reference's own
-// known-answer program test/bitree.cpp (restated in bitree_kat.cpp).  The
-// sampler, the models and the loader have NO golden vectors in the reference
-// and the reference itself cannot be built here (it needs Eigen3, Boost and
-// g2o, none of which are installed), so for those parts parity is UNPINNED:
-// they are a careful operation-by-operation restatement only.
+// Parity status.  PINNED against the reference itself:
+//   * the generic tree (`bitree`, integer groups, binary_search) by the reference's own
+//     known-answer program test/bitree.cpp (restated in bitree_kat.cpp);
+//   * the Plaza loader (GT / DR files, dt), bitree<pose> push_back_accumulated and get, pose
+//     inverse and composition, velocity_slip_model::observe and wrap_angle by the one output
+//     of the reference program that ships with it, input/Plaza{1,2}/controls.txt
+//     (src/dataset.cpp:96-109): controls_txt_rows() below reproduces all 13 747 rows as text;
+//   * the random stream by this toolchain's libstdc++ <random>.
+// UNPINNED (no golden vectors in the reference, and the reference cannot be built here: it
+// needs Eigen3, Boost and g2o, none of which are installed): proposal sampling
+// (inv_observe, polar), the normal log densities, the range-only / range-bearing models, the
+// TD-file de-duplication and the Metropolis-Hastings loop of mcmc_slam / multi_mcmc.  Those
+// are an operation-by-operation restatement only.
 //
 // Third-party arithmetic restated explicitly (so results do not depend on the
 // standard library or on Eigen/Boost being present):
@@ -518,18 +525,40 @@ struct dataset {
   }
 };
 
-// src/dataset.cpp:17-112 -- Plaza range-only text loader (ground truth and the
-// controls.txt side effect are not part of the path and are left out; only the
-// GT file's first row is read: it defines the start time, :34-36).
-inline dataset read_range_only_data(const std::string& dir, const std::string& name) {
+// Ground truth as src/dataset.cpp:30-58 builds it (slam_result_impl): the first row of the GT file
+// is the initial state, every later row is stored relative to it with push_back_accumulated;
+// surveyed landmark positions by id.
+struct ground_truth {
+  pose initial_state;
+  bitree<pose> trajectory;
+  std::map<std::size_t, position> features;
+};
+
+// src/dataset.cpp:17-112 -- Plaza range-only text loader.  `truth`, when given, receives the
+// ground truth of :30-58 (the sampler does not need it; the loader's controls.txt does).
+inline dataset read_range_only_data(const std::string& dir, const std::string& name, ground_truth* truth = nullptr) {
   dataset d;
   double start_timestamp;
-  {
+  {  // :30-46
     std::ifstream gt(dir + "/" + name + "/" + name + "_GT.txt");
     if (!gt) throw std::runtime_error("cannot open " + name + "_GT.txt under " + dir);
     double t, x, y, b;
     gt >> t >> x >> y >> b;
     start_timestamp = t;
+    if (truth) {
+      const pose initial_state = pose::cartesian(x, y, b);
+      truth->initial_state = initial_state;
+      while (gt >> t >> x >> y >> b) {
+        const pose state = -initial_state + pose::cartesian(x, y, b);
+        truth->trajectory.push_back_accumulated(state);
+      }
+    }
+  }
+  if (truth) {  // :49-58
+    std::ifstream tl(dir + "/" + name + "/" + name + "_TL.txt");
+    if (!tl) throw std::runtime_error("cannot open " + name + "_TL.txt");
+    double id, x, y;
+    while (tl >> id >> x >> y) truth->features.emplace(std::size_t(std::round(id)), position::cartesian(x, y));
   }
   {  // :65-76
     std::ifstream dr(dir + "/" + name + "/" + name + "_DR.txt");
@@ -554,6 +583,23 @@ inline dataset read_range_only_data(const std::string& dir, const std::string& n
     }
   }
   return d;
+}
+
+// The rows of the controls.txt the reference's loader writes next to the logs (src/dataset.cpp:96-109):
+// per timestep dt, velocity_slip_model::observe(ground-truth pose change) / dt (3 numbers) and the
+// commanded control (2 numbers).  out[t] = {dt, actual v, actual w, actual g, commanded v, commanded w}.
+inline std::vector<std::array<double, 6>> controls_txt_rows(const dataset& d, const ground_truth& truth) {
+  std::vector<std::array<double, 6>> rows;
+  for (std::size_t t = 0; t < d.current_timestep(); ++t) {
+    const double dt = d.timedelta(t);
+    const pose pose_delta = truth.trajectory[t];
+    double actual[3];
+    velocity_slip_model::observe(pose_delta, actual);
+    for (double& a : actual) a /= dt;
+    const std::array<double, 3>& commanded = d.controls[t];
+    rows.push_back({dt, actual[0], actual[1], actual[2], commanded[0], commanded[1]});
+  }
+  return rows;
 }
 
 // ---------------------------------------------------------------------------

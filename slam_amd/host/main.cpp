@@ -58,7 +58,7 @@ const char* const kFlags[] = {"dataset", "dataset-dir", "mcmc-slam", "mcmc-steps
                               "waypoint-proximity", "sensor-range-max", "sensor-range-min", "robot-speed",
                               "robot-max-steering", "robot-max-steering-rate", "controller-paramP",
                               "controller-paramD", "controller-smoothing", "sensor-bearing-stddev", "split-slices",
-                              "split-min-observations"};
+                              "split-min-observations", "controls-out"};
 const char* const kSwitches[] = {"mcmc-slam", "multi-mcmc", "dump-loader", "help"};
 
 options parse(int argc, char** argv) {
@@ -91,7 +91,7 @@ int main(int argc, char** argv) try {
               "                [--mcmc-slam --mcmc-steps N --mcmc-end-steps N]\n"
               "                [--multi-mcmc --multi-mcmc-chains C --multi-mcmc-end-steps N] [--seed S]\n"
               "                [--sensor-range-stddev X] [--velmodel-alpha1..6 X] [--dump-loader] [--dump-data PREFIX]\n"
-              "                [--dataset-cache FILE]");
+              "                [--dataset-cache FILE] [--controls-out FILE]");
     return opt.has("help") ? 0 : 2;
   }
 
@@ -147,7 +147,12 @@ int main(int argc, char** argv) try {
 #ifndef SLAM_HIP_RANGE_BEARING
     if (!cache.empty()) slam::write_dataset_cache(*dataset, cache);
   } else {
-    dataset = slam::read_range_only_data(opt.str("dataset-dir", "input"), opt.str("dataset", ""));
+    // --controls-out FILE: the controls.txt the reference's loader writes into the data directory
+    // (src/dataset.cpp:96-109), to a file of the caller's choice
+    std::shared_ptr<slam::range_only_ground_truth> ground_truth;
+    dataset = slam::read_range_only_data(opt.str("dataset-dir", "input"), opt.str("dataset", ""),
+                                         opt.has("controls-out") ? &ground_truth : nullptr);
+    if (ground_truth) slam::write_controls_txt(*dataset, *ground_truth, opt.str("controls-out", ""));
     if (!cache.empty()) slam::write_dataset_cache(*dataset, cache);
 #endif
   }

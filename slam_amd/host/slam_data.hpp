@@ -171,14 +171,18 @@ class dataset_impl {
 
 using range_only_dataset = dataset_impl<planar_robot::velocity_slip_model, planar_robot::range_only_model>;
 
+using range_only_ground_truth = slam_result_impl<planar_robot::pose, planar_robot::position>;
+
 // CMU Plaza range-only logs: <name>_GT.txt (time x y heading; the first row gives
-// the start time), <name>_DR.txt (time, distance and heading increments; control
-// = increment / dt, third component 0), <name>_TD.txt (time antenna beacon
-// range; the timestep is found from the time since start, the first reading per
-// (timestep, beacon) wins).  The reference's loader also reads the beacon
-// survey and the GPS track as ground truth and writes a controls.txt into the
-// data directory; neither is part of the sampler's input and both are left out.
-inline std::shared_ptr<range_only_dataset> read_range_only_data(const std::string& dir, const std::string& name) {
+// the start time and the initial pose), <name>_DR.txt (time, distance and heading
+// increments; control = increment / dt, third component 0), <name>_TD.txt (time
+// antenna beacon range; the timestep is found from the time since start, the first
+// reading per (timestep, beacon) wins), <name>_TL.txt (beacon id x y).  The sampler
+// needs only the dataset; `ground_truth`, when given, receives what the reference's
+// loader builds beside it (src/dataset.cpp:30-58): the GPS track relative to its first
+// pose and the surveyed beacon positions.
+inline std::shared_ptr<range_only_dataset> read_range_only_data(
+    const std::string& dir, const std::string& name, std::shared_ptr<range_only_ground_truth>* ground_truth = nullptr) {
   auto open = [&](const char* suffix) {
     const std::string path = dir + "/" + name + "/" + name + suffix;
     std::ifstream f(path);
@@ -189,8 +193,20 @@ inline std::shared_ptr<range_only_dataset> read_range_only_data(const std::strin
   double start;
   {
     auto gt = open("_GT.txt");
-    double x, y, b;
+    double t, x, y, b;
     if (!(gt >> start >> x >> y >> b)) throw std::runtime_error(name + "_GT.txt is empty");
+    if (ground_truth) {
+      auto truth = std::make_shared<range_only_ground_truth>();
+      const auto first = planar_robot::pose::cartesian(x, y, b);
+      truth->set_initial_state(first);
+      while (gt >> t >> x >> y >> b)
+        truth->get_trajectory().push_back_accumulated(-first + planar_robot::pose::cartesian(x, y, b));
+      auto tl = open("_TL.txt");
+      double id;
+      while (tl >> id >> x >> y)
+        truth->get_feature_map().emplace(std::size_t(std::round(id)), planar_robot::position::cartesian(x, y));
+      *ground_truth = truth;
+    }
   }
   {
     auto dr = open("_DR.txt");
@@ -216,6 +232,25 @@ inline std::shared_ptr<range_only_dataset> read_range_only_data(const std::strin
     }
   }
   return out;
+}
+
+// The table the reference's loader leaves next to the logs as controls.txt (src/dataset.cpp:96-109),
+// written to a path of the caller's choice instead: per timestep dt, the control that the ground-truth
+// pose change amounts to (velocity_slip_model::observe / dt) and the commanded one.
+inline void write_controls_txt(const range_only_dataset& data, const range_only_ground_truth& truth,
+                               const std::string& path) {
+  std::ofstream controls(path);
+  if (!controls) throw std::runtime_error("cannot write " + path);
+  controls << "# dt, actual v, actual w, actual g, commanded v, commanded w\n";
+  for (timestep_type t{0}; t < data.current_timestep(); ++t) {
+    const double dt = data.timedelta(t);
+    const planar_robot::pose pose_delta = truth.get_trajectory()[t];
+    auto actual = planar_robot::velocity_slip_model::observe(pose_delta);
+    for (int i = 0; i < 3; ++i) actual(i) /= dt;
+    const auto& commanded = data.control(t);
+    controls << dt << ' ' << actual(0) << ' ' << actual(1) << ' ' << actual(2) << ' ' << commanded(0) << ' '
+             << commanded(1) << '\n';
+  }
 }
 
 // Binary cache of a range-only dataset: what read_range_only_data produces, as

@@ -152,7 +152,27 @@ struct independent_normal {
   }
 };
 
+// src/utility/geometry.hpp:8-16: into [-pi, pi)
+inline double wrap_angle(double angle) {
+  constexpr double pi = 3.14159265358979323846;
+  angle = std::fmod(angle, 2.0 * pi);
+  if (angle < -pi)
+    angle += 2.0 * pi;
+  else if (angle >= pi)
+    angle -= 2.0 * pi;
+  return angle;
+}
+
 struct velocity_slip_model : independent_normal<3, pose> {
+  // velocity_model.hpp:37-49: pose change -> (arc length, turn, slip)
+  static vector_type observe(const pose& dp) {
+    const double r = 0.5 * (dp.x() * dp.x() + dp.y() * dp.y()) / dp.y();
+    if (std::isfinite(r)) {
+      const double alpha = r >= 0 ? std::atan2(dp.x(), r - dp.y()) : std::atan2(-dp.x(), dp.y() - r);
+      return from_steering(r * alpha, alpha, wrap_angle(dp.bearing() - alpha));
+    }
+    return from_steering(dp.x(), 0.0, dp.bearing());
+  }
   // velocity_model.hpp:51-63
   static pose inv_observe(const vector_type& control) {
     const double s = control(0), alpha = control(1), beta = control(2), r = s / alpha;
@@ -365,11 +385,14 @@ struct slam_result : public data_source {
 template <class State, class Feature>
 class slam_result_impl : public slam_result<State, Feature> {
   using base = slam_result<State, Feature>;
+  State initial_state;
   typename base::trajectory_type trajectory;
   typename base::feature_map_type map;
 
  public:
   void timestep(timestep_type) override {}
+  void set_initial_state(const State& s) { initial_state = s; }
+  State get_initial_state() const override { return initial_state; }
   timestep_type current_timestep() const override { return timestep_type(trajectory.size()); }
   typename base::trajectory_type& get_trajectory() { return trajectory; }
   typename base::feature_map_type& get_feature_map() { return map; }

@@ -64,6 +64,18 @@ def uniform_sequence(seed, n):
     return out
 
 
+def plaza_controls_rows(plaza_dir, name):
+    """The six columns of the reference loader's controls.txt (src/dataset.cpp:96-109), recomputed
+    by the oracle from the logs: [T, 6] = dt, actual v, w, g, commanded v, w."""
+    n = lib().ora_plaza_controls_rows(plaza_dir.encode(), name.encode(), None, ctypes.c_uint32(0))
+    if n < 0:
+        raise RuntimeError(f"oracle could not load {name} under {plaza_dir}")
+    rows = np.empty((n, 6), dtype=np.float64)
+    got = lib().ora_plaza_controls_rows(plaza_dir.encode(), name.encode(), _p(rows), ctypes.c_uint32(n))
+    assert got == n
+    return rows
+
+
 class World:
     def __init__(self):
         self.L = lib()

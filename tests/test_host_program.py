@@ -104,6 +104,16 @@ def test_simulator_matches_oracle(seed, repetitions, tmp_path):
     assert np.array_equal(d["dt"][:, None] * d["controls"], inp["ctrl_mean"])
 
 
+@pytest.mark.parametrize("name", ["Plaza1", "Plaza2"])
+def test_host_loader_reproduces_the_reference_controls_txt(name, tmp_path):
+    """The host loader's ground truth, pose arithmetic and bitree<pose> against the controls.txt the reference's
+    own loader wrote (src/dataset.cpp:96-109, shipped as input/<name>/controls.txt): byte for byte."""
+    out = tmp_path / "controls.txt"
+    run("--dataset", name, "--dataset-dir", PLAZA, "--dump-loader", "--controls-out", str(out))
+    with open(os.path.join(PLAZA, name, "controls.txt"), "rb") as f:
+        assert out.read_bytes() == f.read()
+
+
 def test_dataset_cache_rejects_garbage(tmp_path):
     bad = tmp_path / "bad.slamro"
     bad.write_bytes(b"not a cache at all" * 8)

@@ -36,6 +36,30 @@ def test_seed_sequence_known_values():
     assert list(s) == [3499211612, 581869302, 3890346734]
 
 
+@pytest.mark.parametrize("name", ["Plaza1", "Plaza2"])
+def test_loader_and_pose_arithmetic_against_the_reference_controls_txt(name, plaza_dir):
+    """The one output of the reference program that ships with it: input/<name>/controls.txt, written by the
+    reference's own loader (src/dataset.cpp:96-109) -- per timestep dt, velocity_slip_model::observe(ground-truth
+    pose change) / dt and the commanded control, at the stream's default precision of 6 significant digits.
+    The oracle recomputes all 9 657 + 4 090 rows from the logs; that pins its DR/GT loader and dt, bitree<pose>
+    push_back_accumulated / get (bitree.hpp:256-264, 293-300), pose inverse and composition (pose.hpp:67-76),
+    velocity_slip_model::observe (velocity_model.hpp:37-49) and wrap_angle against the reference itself."""
+    rows = oracle_lib.plaza_controls_rows(plaza_dir, name)
+    with open(os.path.join(plaza_dir, name, "controls.txt")) as f:
+        lines = f.read().splitlines()
+    assert lines[0].startswith("#")
+    ref_lines = lines[1:]
+    assert len(ref_lines) == rows.shape[0] == {"Plaza1": 9657, "Plaza2": 4090}[name]
+    ref = np.array([[float(x) for x in line.split()] for line in ref_lines])
+    # half a unit of the sixth significant digit is 5e-6 relative; nothing may be further away
+    err = np.abs(rows - ref) / np.maximum(np.abs(ref), 1e-300)
+    assert err.max() <= 5.0e-6, f"row {np.unravel_index(np.argmax(err), err.shape)}: rel err {err.max():.3e}"
+    # ... and printed the way operator<< prints a double, the rows are the reference's text
+    mine = ["%g %g %g %g %g %g" % tuple(r) for r in rows]
+    different = [t for t, (a, b) in enumerate(zip(mine, ref_lines)) if a != b]
+    assert not different, f"{len(different)} rows differ as text, first: {different[0]}: {mine[different[0]]!r}"
+
+
 def unhex(x):
     return float.fromhex(x)
 
