@@ -14,8 +14,11 @@ per chain per `--report-every` updates (multi_mcmc's report interval), and the
 step ends with the exchange of those records (all-gather over RCCL when N > 1)
 and the best-chain maximum per interval.  N GPUs run N x 1024 chains (weak scaling), one process per GPU.
 
-Launch: python bench.py [--gpus N --steps K --warmup W]; for N > 1 under
-python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+Launch: python bench.py [--gpus N --steps K --warmup W].  For N > 1 either under
+python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ... (the ranks
+read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), or plainly as
+python bench.py --gpus N: the process then starts the N ranks itself, as fresh child
+processes, before it has touched a GPU.  --gpus that disagrees with WORLD_SIZE is an error.
 """
 import argparse
 import json
@@ -179,11 +182,36 @@ def plaza_wall(name, device, with_cpu):
     return out
 
 
+def launch_ranks(n):
+    """python bench.py --gpus N outside a launcher: N fresh child processes, one rank each, rendezvous on
+    127.0.0.1.  This process has not touched a GPU (nothing GPU-related is imported before this point);
+    it only waits for the children and hands on the worst exit code.  Rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    children = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    codes = [c.wait() for c in children]
+    return max((abs(c) for c in codes), default=0)
+
+
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: start one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...) "
+                         "or run python bench.py --gpus N without a launcher")
     import torch
     import torch.distributed as dist
 
