@@ -288,6 +288,67 @@ int mcmcgpu_write_summaries(mcmcgpu_handle h, void* dev_out);
 int mcmcgpu_export_state(mcmcgpu_handle h, uint32_t chain, void* dev_out);
 int mcmcgpu_import_state(mcmcgpu_handle h, uint32_t chain, const void* dev_in, double log_likelihood);
 
+/* ---- Exchange between handles: RCCL over xGMI -------------------------------------------------
+ * The reference runs all chains in one loop and compares them there (multi_mcmc::update,
+ * src/slam/multi_mcmc.hpp:105-119), reports after every 100 updates (:121-139) and averages them
+ * (:71-73).  With the chains of one job sharded over several handles -- one per GPU, in one process
+ * or in one process per GPU -- those three become collectives, issued by the library on each
+ * handle's stream: an all-gather of the 16-byte chain summaries, a broadcast of one chain's state
+ * from the rank that owns it, an all-reduce of the averaging sums.  Rank r holds global chains
+ * [r * slots_per_rank, r * slots_per_rank + its chain count); ranks may hold fewer chains than
+ * slots_per_rank, the unused slots come back with log_likelihood = -infinity.  librccl is opened
+ * when the first of these calls needs it.  A handle WITHOUT a communicator behaves as a
+ * communicator of one rank (slots_per_rank = max_chains): every call below then works locally,
+ * without RCCL.  Attaching a communicator allocates the exchange buffers (the one allocation
+ * outside mcmcgpu_create).
+ *
+ *   mcmcgpu_comm_unique_id   ncclGetUniqueId: 128 bytes rank 0 hands to the other processes;
+ *   mcmcgpu_comm_init        ncclCommInitRank for one handle per process;
+ *   mcmcgpu_comm_init_all    ncclCommInitAll for n handles of ONE process on n different devices,
+ *                            rank = position in the array; collectives of such handles issued from
+ *                            one thread go between mcmcgpu_group_begin / mcmcgpu_group_end
+ *                            (ncclGroupStart / ncclGroupEnd);
+ *   mcmcgpu_comm_info        ranks, this handle's rank, slots per rank. */
+#define MCMCGPU_UNIQUE_ID_BYTES 128
+int mcmcgpu_comm_unique_id(unsigned char* id);
+int mcmcgpu_comm_init(mcmcgpu_handle h, int nranks, int rank, const unsigned char* id, uint32_t slots_per_rank);
+int mcmcgpu_comm_init_all(mcmcgpu_handle* handles, int n, uint32_t slots_per_rank);
+int mcmcgpu_comm_info(mcmcgpu_handle h, int* nranks, int* rank, uint32_t* slots_per_rank);
+int mcmcgpu_group_begin(void);
+int mcmcgpu_group_end(void);
+
+/* All-gather of chain summaries (stream-ordered, every rank calls it):
+ *   mcmcgpu_allgather_summaries  the chains' current summaries, one interval;
+ *   mcmcgpu_allgather_reports    the report records of the last mcmcgpu_run_reported /
+ *                                mcmcgpu_run_split_reported that used the library's own buffer
+ *                                (dev_out == NULL), all its intervals;
+ *   mcmcgpu_get_gathered         waits and copies what was gathered to HOST memory:
+ *                                out[(rank * intervals + interval) * slots + slot]; out may be NULL
+ *                                to ask for the three sizes only. */
+int mcmcgpu_allgather_summaries(mcmcgpu_handle h);
+int mcmcgpu_allgather_reports(mcmcgpu_handle h);
+int mcmcgpu_get_gathered(mcmcgpu_handle h, mcmcgpu_chain_summary* out, uint32_t capacity_records, uint32_t* ranks,
+                         uint32_t* intervals, uint32_t* slots_per_rank);
+
+/* The best chain's state to every rank (what max_likelihood points at, multi_mcmc.hpp:115-117, once
+ * a result is asked for): rank `root` packs its chain `chain` (ignored on the other ranks), the
+ * library broadcasts it into a buffer of each handle; mcmcgpu_get_broadcast_state copies that to
+ * HOST memory as rel_poses [T][3] and parent-relative landmark estimates [F][2] (either may be NULL). */
+int mcmcgpu_broadcast_state(mcmcgpu_handle h, int root, uint32_t chain);
+int mcmcgpu_get_broadcast_state(mcmcgpu_handle h, double* rel_poses, double* feat_estimate);
+
+/* multi_mcmc::get_average over the chains of ALL ranks (src/slam/average_slam_result.hpp:27-54),
+ * in three phases every rank goes through in turn: 0 = the base vectors (global chain 0) computed
+ * on rank 0 and broadcast; 1 = each rank's sum of differences from the base, all-reduced; 2 = the
+ * average itself, copied to HOST memory in the layout of mcmcgpu_get_average (total_chains = chains
+ * of all ranks; the pointers are only used in phase 2 and may be NULL).  mcmcgpu_average_buffer
+ * copies the base (which = 0) or the sum (1) between the handle's buffer and HOST memory (write = 0:
+ * to the host, 1: from it): for handles that share a GPU, where RCCL cannot run, the caller carries
+ * the two vectors between them itself. */
+int mcmcgpu_average_collective(mcmcgpu_handle h, int phase, uint32_t total_chains, double* cumulative_poses,
+                               double* features_world);
+int mcmcgpu_average_buffer(mcmcgpu_handle h, int which, int write, double* host);
+
 /* Hand-off of one chain's estimate to a CPU consumer WITHOUT stalling the
  * sampler -- the candidate loop of src/main.cpp:331-337 (10 000 updates, then
  * g2o_clustering::add(*mcmc_slam), which reads get_trajectory / get_feature_map
@@ -322,7 +383,9 @@ int mcmcgpu_snapshot_wait(mcmcgpu_handle h, uint32_t* timesteps, double* rel_pos
  *                          chain 0) and copies the result to HOST memory; the
  *                          caller rebuilds the relative-pose tree from the
  *                          accumulated poses as push_back_accumulated does
- *                          (src/utility/bitree.hpp:294-300). */
+ *                          (src/utility/bitree.hpp:294-300).
+ * A NULL dev_base / dev_sum stands for a buffer of the handle itself (the ones
+ * mcmcgpu_average_collective and mcmcgpu_average_buffer work on). */
 int mcmcgpu_average_base(mcmcgpu_handle h, uint32_t chain, void* dev_base);
 int mcmcgpu_average_sum(mcmcgpu_handle h, const void* dev_base, int32_t skip_chain, void* dev_sum);
 int mcmcgpu_average_finish(mcmcgpu_handle h, void* dev_base, const void* dev_sum, uint32_t total_chains);

@@ -79,6 +79,19 @@ EXPORTS = [
     "mcmcgpu_get_traffic_counters",
     "mcmcgpu_get_trace",
     "mcmcgpu_write_summaries",
+    "mcmcgpu_comm_unique_id",
+    "mcmcgpu_comm_init",
+    "mcmcgpu_comm_init_all",
+    "mcmcgpu_comm_info",
+    "mcmcgpu_group_begin",
+    "mcmcgpu_group_end",
+    "mcmcgpu_allgather_summaries",
+    "mcmcgpu_allgather_reports",
+    "mcmcgpu_get_gathered",
+    "mcmcgpu_broadcast_state",
+    "mcmcgpu_get_broadcast_state",
+    "mcmcgpu_average_collective",
+    "mcmcgpu_average_buffer",
     "mcmcgpu_snapshot_begin",
     "mcmcgpu_snapshot_wait",
     "mcmcgpu_average_base",
@@ -155,6 +168,16 @@ def selftest_scan(a, b, p, device=0):
     if rc != 0:
         raise RuntimeError(f"mcmcgpu_selftest_scan failed ({rc}): {lib.mcmcgpu_last_error(None).decode()}")
     return oa, ob
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the library: 128 bytes for mcmcgpu_comm_init on every rank."""
+    lib = load_library()
+    buf = (ctypes.c_ubyte * 128)()
+    rc = lib.mcmcgpu_comm_unique_id(buf)
+    if rc != 0:
+        raise RuntimeError(f"mcmcgpu_comm_unique_id failed ({rc}): {lib.mcmcgpu_last_error(None).decode()}")
+    return bytes(buf)
 
 
 def scan_poses_static(chains, n, rel_x_ptr, rel_y_ptr, rel_th_ptr, rel_stride, cum_xy_ptr, cum_th_ptr, cum_stride,
@@ -309,6 +332,53 @@ class McmcGpu:
         self._check(self.lib.mcmcgpu_get_ladders(self.h, _ptr(beta), _ptr(slot), _ptr(rll), ctypes.byref(att),
                                                  ctypes.byref(swp)), "mcmcgpu_get_ladders")
         return beta, slot, rll, att.value, swp.value
+
+    # ---- exchange between handles (RCCL inside the library) ----
+    def comm_init(self, nranks, rank, unique_id, slots_per_rank):
+        """ncclCommInitRank for this handle; unique_id = the 128 bytes of comm_unique_id() made on rank 0."""
+        buf = (ctypes.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
+        self._check(self.lib.mcmcgpu_comm_init(self.h, ctypes.c_int(nranks), ctypes.c_int(rank), buf,
+                                               ctypes.c_uint32(slots_per_rank)), "mcmcgpu_comm_init")
+
+    def comm_info(self):
+        n, r, s = ctypes.c_int(), ctypes.c_int(), ctypes.c_uint32()
+        self._check(self.lib.mcmcgpu_comm_info(self.h, ctypes.byref(n), ctypes.byref(r), ctypes.byref(s)), "mcmcgpu_comm_info")
+        return n.value, r.value, s.value
+
+    def allgather_summaries(self):
+        self._check(self.lib.mcmcgpu_allgather_summaries(self.h), "mcmcgpu_allgather_summaries")
+
+    def allgather_reports(self):
+        self._check(self.lib.mcmcgpu_allgather_reports(self.h), "mcmcgpu_allgather_reports")
+
+    def gathered(self):
+        """What the last all-gather brought: structured array [ranks, intervals, slots]."""
+        r, k, s = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+        self._check(self.lib.mcmcgpu_get_gathered(self.h, None, ctypes.c_uint32(0), ctypes.byref(r), ctypes.byref(k),
+                                                  ctypes.byref(s)), "mcmcgpu_get_gathered")
+        out = np.zeros((r.value, k.value, s.value), dtype=CHAIN_SUMMARY)
+        self._check(self.lib.mcmcgpu_get_gathered(self.h, _ptr(out), ctypes.c_uint32(out.size), ctypes.byref(r),
+                                                  ctypes.byref(k), ctypes.byref(s)), "mcmcgpu_get_gathered")
+        return out
+
+    def broadcast_state(self, root, chain):
+        self._check(self.lib.mcmcgpu_broadcast_state(self.h, ctypes.c_int(root), ctypes.c_uint32(chain)),
+                    "mcmcgpu_broadcast_state")
+
+    def get_broadcast_state(self):
+        T, F, _ = self.dims()
+        rel, est = np.empty((T, 3)), np.empty((F, 2))
+        self._check(self.lib.mcmcgpu_get_broadcast_state(self.h, _ptr(rel), _ptr(est)), "mcmcgpu_get_broadcast_state")
+        return rel, est
+
+    def average_collective(self, total_chains):
+        """All three phases in a row: right for one handle per process (or a single handle)."""
+        T, F, _ = self.dims()
+        cum, feat = np.empty((T, 3)), np.empty((F, 2))
+        for phase in (0, 1, 2):
+            self._check(self.lib.mcmcgpu_average_collective(self.h, ctypes.c_int(phase), ctypes.c_uint32(total_chains),
+                                                            _ptr(cum), _ptr(feat)), "mcmcgpu_average_collective")
+        return cum, feat
 
     def snapshot_begin(self, chain):
         """Queue a copy of one chain's estimate to pinned host memory; later launches may be queued behind it."""

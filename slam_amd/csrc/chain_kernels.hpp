@@ -2099,6 +2099,22 @@ __global__ void summaries_kernel(Dev d, mcmcgpu_chain_summary* out) {
   out[c].accepts = uint32_t(d.n_accepts[c]);
 }
 
+// Report records [intervals][C] laid out for an all-gather between handles that may hold different
+// numbers of chains: [intervals][slots] with slots >= C, the unused slots filled with a record no
+// arg-max can pick (log likelihood -inf, no updates).
+__global__ void pack_records_kernel(const mcmcgpu_chain_summary* src, uint32_t C, uint32_t intervals,
+                                    mcmcgpu_chain_summary* dst, uint32_t slots) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= intervals * slots) return;
+  const uint32_t k = i / slots, s = i % slots;
+  mcmcgpu_chain_summary r;
+  r.log_likelihood = -__builtin_huge_val();
+  r.updates = 0;
+  r.accepts = 0;
+  if (s < C) r = src[size_t(k) * C + s];
+  dst[i] = r;
+}
+
 // Recomputes both weight trees of chains [first, first + gridDim.x) from their
 // current estimates (each edge weight is a function of the edge's current
 // value: mcmc_slam.hpp:240-241, 262-263, 388-390).  A tree node only depends on

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "chain_kernels.hpp"
+#include "rccl_loader.hpp"
 
 using namespace mg;
 
@@ -75,6 +76,16 @@ struct mcmcgpu_ctx {
   RngState exchange_rng{};
   double* exch_u = nullptr;                 // [C/2 + 1] uniforms of one exchange sweep
   unsigned long long* exch_counts = nullptr;  // attempts, swaps
+  // exchange with other handles (mcmcgpu_comm_*): communicator, this handle's place in it, buffers
+  ncclComm_t comm = nullptr;
+  int comm_ranks = 0, comm_rank = 0;
+  uint32_t comm_slots = 0;                         // records per rank and report interval in a gather
+  mcmcgpu_chain_summary* gather_send = nullptr;    // [kMaxOwnReports][comm_slots]
+  mcmcgpu_chain_summary* gather_recv = nullptr;    // [comm_ranks][kMaxOwnReports][comm_slots]
+  uint32_t gathered_intervals = 0;
+  double* avg_base = nullptr;                      // [3 Tcap + 2 Fcap] averaging: the base vectors
+  double* avg_sum = nullptr;                       // [3 Tcap + 2 Fcap] averaging: the summed differences
+  double* bcast = nullptr;                         // [3 Tcap + 2 Fcap] a chain's packed state, as broadcast
   std::string error;
 };
 
@@ -370,6 +381,66 @@ int rebuild_impl(mcmcgpu_handle h, uint32_t first, uint32_t count) {
   return 0;
 }
 
+// ---- exchange between handles ---------------------------------------------------------------------
+#define RCCL_TRY(h, expr)                                                                          \
+  do {                                                                                             \
+    ncclResult_t r_ = (expr);                                                                      \
+    if (r_ != ncclSuccess)                                                                         \
+      return fail(h, MCMCGPU_ERR_HIP, std::string(#expr) + ": " + rccl().GetErrorString(r_));      \
+  } while (0)
+
+int need_rccl(mcmcgpu_handle h) {
+  if (!rccl().error.empty()) return fail(h, MCMCGPU_ERR_STATE, rccl().error);
+  return 0;
+}
+
+// Doubles of one packed estimate: accumulated poses [T][3], landmark positions [F][2].
+size_t packed_capacity(const mcmcgpu_ctx* h) { return 3 * size_t(h->d.Tcap) + 2 * size_t(h->d.Fcap); }
+
+// Device buffers of the exchange entry points, for `ranks` ranks of `slots` records each.  The only
+// allocation outside mcmcgpu_create: made when a communicator is attached, or at the first exchange
+// call of a handle without one (which behaves as a communicator of one rank).
+int ensure_exchange_buffers(mcmcgpu_handle h, int ranks, uint32_t slots) {
+  if (h->gather_recv && h->comm_ranks == ranks && h->comm_slots == slots) return 0;
+  for (void* p : {static_cast<void*>(h->gather_send), static_cast<void*>(h->gather_recv)}) {
+    if (!p) continue;
+    h->allocations.erase(std::find(h->allocations.begin(), h->allocations.end(), p));
+    HIP_TRY(h, hipFree(p));
+  }
+  h->gather_send = h->gather_recv = nullptr;
+  h->comm_ranks = ranks;
+  h->comm_slots = slots;
+  int rc = dev_alloc(h, &h->gather_send, size_t(kMaxOwnReports) * slots);
+  if (!rc) rc = dev_alloc(h, &h->gather_recv, size_t(ranks) * kMaxOwnReports * slots);
+  if (!rc && !h->avg_base) rc = dev_alloc(h, &h->avg_base, packed_capacity(h));
+  if (!rc && !h->avg_sum) rc = dev_alloc(h, &h->avg_sum, packed_capacity(h));
+  if (!rc && !h->bcast) rc = dev_alloc(h, &h->bcast, packed_capacity(h));
+  return rc;
+}
+int default_exchange_buffers(mcmcgpu_handle h) {  // a handle without a communicator: one rank, all its chains
+  if (h->gather_recv) return 0;
+  return ensure_exchange_buffers(h, 1, h->cfg.max_chains);
+}
+
+// `intervals` rows of this handle's records (src: [intervals][chains]) to every rank; afterwards
+// gather_recv holds [ranks][intervals][slots].
+int gather_records(mcmcgpu_handle h, const mcmcgpu_chain_summary* src, uint32_t intervals) {
+  if (int rc = default_exchange_buffers(h)) return rc;
+  if (h->chains > h->comm_slots) return fail(h, MCMCGPU_ERR_CAPACITY, "more chains than the communicator's slots per rank");
+  const uint32_t n = intervals * h->comm_slots;
+  mcmcgpu_chain_summary* send = h->comm ? h->gather_send : h->gather_recv;  // alone: packed straight into place
+  if (n) {
+    hipLaunchKernelGGL(pack_records_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, src, h->chains, intervals, send,
+                       h->comm_slots);
+    HIP_TRY(h, hipGetLastError());
+    if (h->comm)
+      RCCL_TRY(h, rccl().AllGather(send, h->gather_recv, size_t(n) * sizeof(mcmcgpu_chain_summary), ncclChar, h->comm,
+                                   h->stream));
+  }
+  h->gathered_intervals = intervals;
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -520,6 +591,7 @@ void mcmcgpu_destroy(mcmcgpu_handle h) {
     (void)hipEventDestroy(ev.start);
     (void)hipEventDestroy(ev.stop);
   }
+  if (h->comm && rccl().CommDestroy) (void)rccl().CommDestroy(h->comm);
   if (h->snap_host) (void)hipHostFree(h->snap_host);
   if (h->snap_event) (void)hipEventDestroy(h->snap_event);
   for (void* p : h->allocations) (void)hipFree(p);
@@ -1303,9 +1375,13 @@ int mcmcgpu_snapshot_wait(mcmcgpu_handle h, uint32_t* timesteps, double* rel_pos
 }
 
 int mcmcgpu_average_base(mcmcgpu_handle h, uint32_t chain, void* dev_base) {
-  if (!h || !dev_base) return fail(h, MCMCGPU_ERR_ARGUMENT, "null argument");
+  if (!h) return MCMCGPU_ERR_ARGUMENT;
   if (chain >= h->chains) return fail(h, MCMCGPU_ERR_ARGUMENT, "chain out of range");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
+  if (!dev_base) {  // the handle's own buffer
+    if (int rc = default_exchange_buffers(h)) return rc;
+    dev_base = h->avg_base;
+  }
   uint32_t nf = 0;
   if (int rc = chains_features(h, &nf)) return rc;
   const uint32_t T = edges_grown(h), n = T + nf;
@@ -1317,8 +1393,13 @@ int mcmcgpu_average_base(mcmcgpu_handle h, uint32_t chain, void* dev_base) {
 }
 
 int mcmcgpu_average_sum(mcmcgpu_handle h, const void* dev_base, int32_t skip_chain, void* dev_sum) {
-  if (!h || !dev_base || !dev_sum) return fail(h, MCMCGPU_ERR_ARGUMENT, "null argument");
+  if (!h) return MCMCGPU_ERR_ARGUMENT;
   HIP_TRY(h, hipSetDevice(h->cfg.device));
+  if (!dev_base || !dev_sum) {  // the handle's own buffers
+    if (int rc = default_exchange_buffers(h)) return rc;
+    if (!dev_base) dev_base = h->avg_base;
+    if (!dev_sum) dev_sum = h->avg_sum;
+  }
   uint32_t nf = 0;
   if (int rc = chains_features(h, &nf)) return rc;
   const uint32_t T = edges_grown(h), n = T + nf;
@@ -1330,9 +1411,14 @@ int mcmcgpu_average_sum(mcmcgpu_handle h, const void* dev_base, int32_t skip_cha
 }
 
 int mcmcgpu_average_finish(mcmcgpu_handle h, void* dev_base, const void* dev_sum, uint32_t total_chains) {
-  if (!h || !dev_base || !dev_sum) return fail(h, MCMCGPU_ERR_ARGUMENT, "null argument");
+  if (!h) return MCMCGPU_ERR_ARGUMENT;
   if (total_chains == 0) return fail(h, MCMCGPU_ERR_ARGUMENT, "total_chains must be positive");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
+  if (!dev_base || !dev_sum) {  // the handle's own buffers
+    if (int rc = default_exchange_buffers(h)) return rc;
+    if (!dev_base) dev_base = h->avg_base;
+    if (!dev_sum) dev_sum = h->avg_sum;
+  }
   uint32_t nf = 0;
   if (int rc = chains_features(h, &nf)) return rc;
   const uint32_t T = edges_grown(h), n = T + nf;
@@ -1361,6 +1447,195 @@ int mcmcgpu_get_average(mcmcgpu_handle h, double* cumulative_poses, double* feat
   if (features_world && nf)
     HIP_TRY(h, hipMemcpyAsync(features_world, base + 3 * T, 2 * size_t(nf) * sizeof(double), hipMemcpyDeviceToHost,
                               h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int mcmcgpu_comm_unique_id(unsigned char* id) {
+  if (!id) return fail(nullptr, MCMCGPU_ERR_ARGUMENT, "null argument");
+  if (int rc = need_rccl(nullptr)) return rc;
+  ncclUniqueId u;
+  mcmcgpu_handle h = nullptr;
+  RCCL_TRY(h, rccl().GetUniqueId(&u));
+  static_assert(sizeof u == MCMCGPU_UNIQUE_ID_BYTES, "unique id size");
+  std::memcpy(id, &u, sizeof u);
+  return 0;
+}
+
+int mcmcgpu_comm_init(mcmcgpu_handle h, int nranks, int rank, const unsigned char* id, uint32_t slots_per_rank) {
+  if (!h || !id) return fail(h, MCMCGPU_ERR_ARGUMENT, "null argument");
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(h, MCMCGPU_ERR_ARGUMENT, "rank out of range");
+  if (slots_per_rank < h->cfg.max_chains) return fail(h, MCMCGPU_ERR_ARGUMENT, "slots_per_rank below the handle's max_chains");
+  if (h->comm) return fail(h, MCMCGPU_ERR_STATE, "the handle already has a communicator");
+  if (int rc = need_rccl(h)) return rc;
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  if (int rc = ensure_exchange_buffers(h, nranks, slots_per_rank)) return rc;
+  ncclUniqueId u;
+  std::memcpy(&u, id, sizeof u);
+  RCCL_TRY(h, rccl().CommInitRank(&h->comm, nranks, u, rank));
+  h->comm_rank = rank;
+  return 0;
+}
+
+int mcmcgpu_comm_init_all(mcmcgpu_handle* handles, int n, uint32_t slots_per_rank) {
+  if (!handles || n < 1) return fail(nullptr, MCMCGPU_ERR_ARGUMENT, "no handles");
+  if (int rc = need_rccl(handles[0])) return rc;
+  std::vector<int> devices(n);
+  for (int i = 0; i < n; ++i) {
+    mcmcgpu_handle h = handles[i];
+    if (!h) return fail(nullptr, MCMCGPU_ERR_ARGUMENT, "null handle");
+    if (h->comm) return fail(h, MCMCGPU_ERR_STATE, "the handle already has a communicator");
+    if (slots_per_rank < h->cfg.max_chains) return fail(h, MCMCGPU_ERR_ARGUMENT, "slots_per_rank below the handle's max_chains");
+    devices[i] = h->cfg.device;
+    for (int k = 0; k < i; ++k)
+      if (devices[k] == devices[i]) return fail(h, MCMCGPU_ERR_ARGUMENT, "RCCL wants every rank on a device of its own");
+  }
+  for (int i = 0; i < n; ++i) {
+    mcmcgpu_handle h = handles[i];
+    HIP_TRY(h, hipSetDevice(h->cfg.device));
+    if (int rc = ensure_exchange_buffers(h, n, slots_per_rank)) return rc;
+  }
+  std::vector<ncclComm_t> comms(n, nullptr);
+  mcmcgpu_handle h0 = handles[0];
+  RCCL_TRY(h0, rccl().CommInitAll(comms.data(), n, devices.data()));
+  for (int i = 0; i < n; ++i) {
+    handles[i]->comm = comms[i];
+    handles[i]->comm_rank = i;
+  }
+  return 0;
+}
+
+int mcmcgpu_comm_info(mcmcgpu_handle h, int* nranks, int* rank, uint32_t* slots_per_rank) {
+  if (!h) return MCMCGPU_ERR_ARGUMENT;
+  if (nranks) *nranks = h->comm ? h->comm_ranks : 1;
+  if (rank) *rank = h->comm ? h->comm_rank : 0;
+  if (slots_per_rank) *slots_per_rank = h->gather_recv ? h->comm_slots : h->cfg.max_chains;
+  return 0;
+}
+
+int mcmcgpu_group_begin(void) {
+  if (int rc = need_rccl(nullptr)) return rc;
+  mcmcgpu_handle h = nullptr;
+  RCCL_TRY(h, rccl().GroupStart());
+  return 0;
+}
+
+int mcmcgpu_group_end(void) {
+  if (int rc = need_rccl(nullptr)) return rc;
+  mcmcgpu_handle h = nullptr;
+  RCCL_TRY(h, rccl().GroupEnd());
+  return 0;
+}
+
+int mcmcgpu_allgather_summaries(mcmcgpu_handle h) {
+  if (!h) return MCMCGPU_ERR_ARGUMENT;
+  if (h->chains == 0) return fail(h, MCMCGPU_ERR_STATE, "no chains");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  // the chains' current summaries go through row 0 of the report buffer
+  hipLaunchKernelGGL(summaries_kernel, dim3((h->chains + 255) / 256), dim3(256), 0, h->stream, h->d, h->reports);
+  HIP_TRY(h, hipGetLastError());
+  h->report_intervals = 1;
+  return gather_records(h, h->reports, 1);
+}
+
+int mcmcgpu_allgather_reports(mcmcgpu_handle h) {
+  if (!h) return MCMCGPU_ERR_ARGUMENT;
+  if (h->chains == 0) return fail(h, MCMCGPU_ERR_STATE, "no chains");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  return gather_records(h, h->reports, h->report_intervals);
+}
+
+int mcmcgpu_get_gathered(mcmcgpu_handle h, mcmcgpu_chain_summary* out, uint32_t capacity_records, uint32_t* ranks,
+                         uint32_t* intervals, uint32_t* slots_per_rank) {
+  if (!h) return MCMCGPU_ERR_ARGUMENT;
+  if (!h->gather_recv) return fail(h, MCMCGPU_ERR_STATE, "nothing has been gathered");
+  const uint32_t R = uint32_t(h->comm_ranks), K = h->gathered_intervals, S = h->comm_slots;
+  if (ranks) *ranks = R;
+  if (intervals) *intervals = K;
+  if (slots_per_rank) *slots_per_rank = S;
+  if (!out) return 0;
+  const size_t n = size_t(R) * K * S;
+  if (capacity_records < n) return fail(h, MCMCGPU_ERR_CAPACITY, "record array too small");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  if (n) HIP_TRY(h, hipMemcpyAsync(out, h->gather_recv, n * sizeof(mcmcgpu_chain_summary), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return check_device_flags(h);
+}
+
+int mcmcgpu_broadcast_state(mcmcgpu_handle h, int root, uint32_t chain) {
+  if (!h) return MCMCGPU_ERR_ARGUMENT;
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  if (int rc = default_exchange_buffers(h)) return rc;
+  const int ranks = h->comm ? h->comm_ranks : 1, rank = h->comm ? h->comm_rank : 0;
+  if (root < 0 || root >= ranks) return fail(h, MCMCGPU_ERR_ARGUMENT, "root rank out of range");
+  if (rank == root)
+    if (int rc = mcmcgpu_export_state(h, chain, h->bcast)) return rc;
+  const size_t n = 3 * size_t(edges_grown(h)) + 2 * size_t(h->d.F);
+  if (h->comm && n) RCCL_TRY(h, rccl().Broadcast(h->bcast, h->bcast, n, ncclDouble, root, h->comm, h->stream));
+  return 0;
+}
+
+int mcmcgpu_get_broadcast_state(mcmcgpu_handle h, double* rel_poses, double* feat_estimate) {
+  if (!h) return MCMCGPU_ERR_ARGUMENT;
+  if (!h->bcast) return fail(h, MCMCGPU_ERR_STATE, "no state has been broadcast");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  const size_t T = edges_grown(h), F = h->d.F;
+  std::vector<double> packed(3 * T + 2 * F);
+  if (!packed.empty())
+    HIP_TRY(h, hipMemcpyAsync(packed.data(), h->bcast, packed.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  for (size_t t = 0; rel_poses && t < T; ++t)
+    for (int k = 0; k < 3; ++k) rel_poses[3 * t + k] = packed[size_t(k) * T + t];
+  for (size_t f = 0; feat_estimate && f < F; ++f)
+    for (int k = 0; k < 2; ++k) feat_estimate[2 * f + k] = packed[3 * T + size_t(k) * F + f];
+  return 0;
+}
+
+int mcmcgpu_average_collective(mcmcgpu_handle h, int phase, uint32_t total_chains, double* cumulative_poses,
+                               double* features_world) {
+  if (!h) return MCMCGPU_ERR_ARGUMENT;
+  if (h->chains == 0) return fail(h, MCMCGPU_ERR_STATE, "no chains initialised");
+  if (phase < 0 || phase > 2) return fail(h, MCMCGPU_ERR_ARGUMENT, "phase must be 0, 1 or 2");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  if (int rc = default_exchange_buffers(h)) return rc;
+  uint32_t nf = 0;
+  if (int rc = chains_features(h, &nf)) return rc;
+  const size_t T = edges_grown(h), n = 3 * T + 2 * size_t(nf);
+  const int rank = h->comm ? h->comm_rank : 0;
+  if (phase == 0) {  // avg_acc's base vectors: global chain 0, on every rank
+    if (rank == 0)
+      if (int rc = mcmcgpu_average_base(h, 0, h->avg_base)) return rc;
+    if (h->comm && n) RCCL_TRY(h, rccl().Broadcast(h->avg_base, h->avg_base, n, ncclDouble, 0, h->comm, h->stream));
+  } else if (phase == 1) {  // the summed differences over all chains of all ranks but the base chain
+    if (int rc = mcmcgpu_average_sum(h, h->avg_base, rank == 0 ? 0 : -1, h->avg_sum)) return rc;
+    if (h->comm && n) RCCL_TRY(h, rccl().AllReduce(h->avg_sum, h->avg_sum, n, ncclDouble, ncclSum, h->comm, h->stream));
+  } else {
+    if (int rc = mcmcgpu_average_finish(h, h->avg_base, h->avg_sum, total_chains)) return rc;
+    if (cumulative_poses && T)
+      HIP_TRY(h, hipMemcpyAsync(cumulative_poses, h->avg_base, 3 * T * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (features_world && nf)
+      HIP_TRY(h, hipMemcpyAsync(features_world, h->avg_base + 3 * T, 2 * size_t(nf) * sizeof(double), hipMemcpyDeviceToHost,
+                                h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  }
+  return 0;
+}
+
+int mcmcgpu_average_buffer(mcmcgpu_handle h, int which, int write, double* host) {
+  if (!h || !host) return fail(h, MCMCGPU_ERR_ARGUMENT, "null argument");
+  if (which < 0 || which > 1) return fail(h, MCMCGPU_ERR_ARGUMENT, "which must be 0 (base) or 1 (sum)");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  if (int rc = default_exchange_buffers(h)) return rc;
+  uint32_t nf = 0;
+  if (int rc = chains_features(h, &nf)) return rc;
+  const size_t bytes = (3 * size_t(edges_grown(h)) + 2 * size_t(nf)) * sizeof(double);
+  double* dev = which == 0 ? h->avg_base : h->avg_sum;
+  if (bytes) {
+    if (write)
+      HIP_TRY(h, hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, h->stream));
+    else
+      HIP_TRY(h, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, h->stream));
+  }
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return 0;
 }

@@ -58,7 +58,7 @@ const char* const kFlags[] = {"dataset", "dataset-dir", "mcmc-slam", "mcmc-steps
                               "waypoint-proximity", "sensor-range-max", "sensor-range-min", "robot-speed",
                               "robot-max-steering", "robot-max-steering-rate", "controller-paramP",
                               "controller-paramD", "controller-smoothing", "sensor-bearing-stddev", "split-slices",
-                              "split-min-observations", "controls-out"};
+                              "split-min-observations", "controls-out", "devices", "exchange"};
 const char* const kSwitches[] = {"mcmc-slam", "multi-mcmc", "dump-loader", "help"};
 
 options parse(int argc, char** argv) {
@@ -91,7 +91,7 @@ int main(int argc, char** argv) try {
               "                [--mcmc-slam --mcmc-steps N --mcmc-end-steps N]\n"
               "                [--multi-mcmc --multi-mcmc-chains C --multi-mcmc-end-steps N] [--seed S]\n"
               "                [--sensor-range-stddev X] [--velmodel-alpha1..6 X] [--dump-loader] [--dump-data PREFIX]\n"
-              "                [--dataset-cache FILE] [--controls-out FILE]");
+              "                [--dataset-cache FILE] [--controls-out FILE] [--devices 0,1,..] [--exchange rccl|host|auto]");
     return opt.has("help") ? 0 : 2;
   }
 
@@ -187,6 +187,24 @@ int main(int argc, char** argv) try {
   cap.features = 4096;
   cap.split_slices = opt.uint("split-slices", cap.split_slices);
   cap.split_min_observations = opt.uint("split-min-observations", cap.split_min_observations);
+  // --devices 0,1,2,3: --multi-mcmc shards its chains over these GPUs (one handle each, RCCL between them);
+  // --exchange rccl|host|auto: how the handles exchange (rccl also with one GPU: a communicator of one rank;
+  // host: through host memory, the only way for handles that share a GPU)
+  if (opt.has("devices")) {
+    const std::string list = opt.str("devices", "");
+    for (std::size_t at = 0; at <= list.size();) {
+      const std::size_t comma = std::min(list.find(',', at), list.size());
+      if (comma > at) cap.devices.push_back(std::atoi(list.substr(at, comma - at).c_str()));
+      at = comma + 1;
+    }
+  }
+  const std::string exchange = opt.str("exchange", "auto");
+  if (exchange == "rccl")
+    cap.exchange = slam::gpu_capacity::exchange_mode::rccl;
+  else if (exchange == "host")
+    cap.exchange = slam::gpu_capacity::exchange_mode::host;
+  else if (exchange != "auto")
+    throw std::runtime_error("--exchange takes rccl, host or auto");
 
   std::shared_ptr<mcmc_slam_type> mcmc_slam;
   std::shared_ptr<mcmc_slam_type::updater> mcmc_slam_updater;
@@ -225,7 +243,15 @@ int main(int argc, char** argv) try {
     }
   }
   if (multi_mcmc) {
-    std::printf("Multi-MCMC-SLAM Chains: %u\n", multi_mcmc->num_chains());
+    std::printf("Multi-MCMC-SLAM Chains: %u on %u handle(s), exchange through %s\n", multi_mcmc->num_chains(),
+                multi_mcmc->num_handles(),
+                multi_mcmc->exchanges_through_rccl() ? "RCCL" : multi_mcmc->num_handles() > 1 ? "host memory" : "nothing");
+    {  // the best chain's estimate, as print_rmse / dump_data would read it (main.cpp:284-305)
+      const auto& trajectory = multi_mcmc->get_trajectory();
+      const auto last = multi_mcmc->get_state(multi_mcmc->current_timestep());
+      std::printf("Multi-MCMC-SLAM best chain: %zu edges, final pose %.17g %.17g %.17g, %zu landmarks\n", trajectory.size(),
+                  last.x(), last.y(), last.bearing(), multi_mcmc->get_feature_map().size());
+    }
     std::printf("Multi-MCMC-SLAM log likelihood: %.17g\n", multi_mcmc->get_log_likelihood());
     // main.cpp:315-320 of the reference: the average over the chains and its likelihood
     const auto average = multi_mcmc->get_average();

@@ -9,9 +9,10 @@
 // random stream -- lives on the GPU behind an mcmcgpu handle
 // (include/mcmcgpu.h); nothing of the sampler runs on the host.
 //
-// slam::multi_mcmc mirrors src/slam/multi_mcmc.hpp:34-169: C chains in ONE
-// handle (one workgroup each), seeded by successive draws of one generator,
-// stepped together, best chain = first maximum of the log likelihoods.
+// slam::multi_mcmc mirrors src/slam/multi_mcmc.hpp:34-169: C chains (one
+// workgroup each) seeded by successive draws of one generator, stepped together,
+// best chain = first maximum of the log likelihoods.  The chains live in one
+// handle, or sharded over one handle per GPU that exchange through RCCL.
 //
 // The class only uses these members of its collaborators, so it compiles
 // against slam_types.hpp / slam_data.hpp here and against the reference's own
@@ -49,6 +50,14 @@ struct gpu_capacity {
   // reading stream over this many workgroups instead (mcmcgpu_run_split), once the data holds at
   // least split_min_observations readings.  0 = never.
   std::uint32_t split_slices = 64, split_min_observations = 200000;
+  // multi_mcmc only: the GPUs its chains are sharded over, one handle each (empty = {device}), and
+  // how the handles exchange chain summaries, the best state and the averaging sums.
+  //   automatic: one handle needs no exchange; several on different GPUs use RCCL; several that share
+  //              a GPU (a rehearsal of the sharded run on one GPU) go through host memory
+  //   rccl:      always through a communicator, also for a single handle (a communicator of one rank)
+  //   host:      always through host memory
+  std::vector<int> devices;
+  enum class exchange_mode { automatic, rccl, host } exchange = exchange_mode::automatic;
 };
 
 namespace detail {
@@ -67,10 +76,17 @@ class device_problem {
   std::vector<std::uint32_t> ot, of;
   std::map<std::size_t, std::uint32_t> dense;
   std::vector<std::size_t> ids;  // dense index -> landmark id
-  // what append_to has handed over so far
-  bool sent_any = false;
-  std::uint32_t sent_T = 0, sent_F = 0;
-  std::size_t sent_N = 0;
+
+ public:
+  // what append_to has handed over to one handle so far
+  struct cursor {
+    bool any = false;
+    std::uint32_t T = 0, F = 0;
+    std::size_t N = 0;
+  };
+
+ private:
+  cursor own;  // for users with a single handle
 
  public:
   // range_bearing_model readings carry a second component (range_bearing_model.hpp:21-40)
@@ -117,6 +133,12 @@ class device_problem {
   // initialiser's estimates per state edge (3 doubles) and per landmark (2 doubles, dense order),
   // as far as they reach.
   void append_to(mcmcgpu_handle h, const std::vector<double>* irel, const std::vector<double>* ifeat) {
+    append_to(h, own, irel, ifeat);
+  }
+  void append_to(mcmcgpu_handle h, cursor& sent, const std::vector<double>* irel, const std::vector<double>* ifeat) {
+    bool& sent_any = sent.any;
+    std::uint32_t &sent_T = sent.T, &sent_F = sent.F;
+    std::size_t& sent_N = sent.N;
     while (!sent_any || sent_T < T()) {
       const std::uint32_t tt = sent_any ? sent_T + 1 : 0;
       std::size_t lo = sent_N, hi = lo;
@@ -337,16 +359,68 @@ class multi_mcmc : public slam_result_of<ControlModel, ObservationModel> {
   using feature_type = typename slam_result_type::feature_type;
   using trajectory_type = typename slam_result_type::trajectory_type;
   using feature_map_type = typename slam_result_type::feature_map_type;
+  using problem_type = detail::device_problem<ControlModel, ObservationModel>;
 
   const std::shared_ptr<const slam_data_type> data;
-  mcmcgpu_handle h = nullptr;
-  detail::device_problem<ControlModel, ObservationModel> problem;
+  // The chains are sharded over one handle per GPU: handle r holds the global chains
+  // [r * slots, r * slots + count[r]), in the order multi_mcmc keeps them in its vector
+  // (multi_mcmc.hpp:164-166).  One GPU = one handle = the whole vector.
+  std::vector<mcmcgpu_handle> hs;
+  std::vector<unsigned int> count;
+  std::vector<typename problem_type::cursor> sent;
+  unsigned int slots = 0;
+  bool use_rccl = false;
+  problem_type problem;
   unsigned int chains, mcmc_end_steps;
   std::uint32_t split_slices = 0, split_min_observations = 0;
   std::size_t next_timestep = 0;
   unsigned int max_likelihood = 0;  // index of the best chain
   double best_ll = 0;
   std::vector<double> chain_ll;     // every chain's log likelihood after its latest round of updates
+
+  mcmcgpu_handle owner_of(unsigned int chain, std::uint32_t* local) const {
+    *local = chain % slots;
+    return hs[chain / slots];
+  }
+  void group_begin() const {
+    if (use_rccl && hs.size() > 1) detail::check(nullptr, mcmcgpu_group_begin(), "mcmcgpu_group_begin");
+  }
+  void group_end() const {
+    if (use_rccl && hs.size() > 1) detail::check(nullptr, mcmcgpu_group_end(), "mcmcgpu_group_end");
+  }
+
+  // All-gather of the chains' summaries (reports = false) or of the report records of the launch
+  // just queued (reports = true); returns them as [interval][global chain].  Through RCCL every
+  // handle ends up with all records and handle 0's copy is read; handles that share a GPU gather
+  // their own records only and the host stitches them.
+  std::vector<mcmcgpu_chain_summary> gather(bool reports, std::uint32_t* intervals_out) const {
+    group_begin();
+    for (mcmcgpu_handle h : hs)
+      detail::check(h, reports ? mcmcgpu_allgather_reports(h) : mcmcgpu_allgather_summaries(h),
+                    reports ? "mcmcgpu_allgather_reports" : "mcmcgpu_allgather_summaries");
+    group_end();
+    std::vector<mcmcgpu_chain_summary> out, part;
+    std::uint32_t K = 0;
+    auto place = [&](std::uint32_t first_rank, std::uint32_t R, std::uint32_t S) {  // part: [R][K][S]
+      if (out.empty()) out.resize(std::size_t(K) * chains);
+      for (std::uint32_t r = 0; r < R; ++r)
+        for (std::uint32_t k = 0; k < K; ++k)
+          for (std::uint32_t s = 0; s < count[first_rank + r]; ++s)
+            out[std::size_t(k) * chains + std::size_t(first_rank + r) * slots + s] = part[(std::size_t(r) * K + k) * S + s];
+    };
+    const std::size_t readers = use_rccl ? 1 : hs.size();
+    for (std::size_t g = 0; g < readers; ++g) {
+      std::uint32_t R = 0, S = 0;
+      detail::check(hs[g], mcmcgpu_get_gathered(hs[g], nullptr, 0, &R, &K, &S), "mcmcgpu_get_gathered");
+      part.resize(std::size_t(R) * K * S);
+      detail::check(hs[g], mcmcgpu_get_gathered(hs[g], part.data(), std::uint32_t(part.size()), &R, &K, &S), "mcmcgpu_get_gathered");
+      place(std::uint32_t(g), R, S);
+    }
+    if (use_rccl)  // the other handles' gathers are waited for as well, and their error flags looked at
+      for (std::size_t g = 1; g < hs.size(); ++g) detail::check(hs[g], mcmcgpu_sync(hs[g]), "mcmcgpu_sync");
+    *intervals_out = K;
+    return out;
+  }
 
   // The comparison loop of multi_mcmc::update (multi_mcmc.hpp:109-118) for one round.  The
   // reference steps chain after chain and compares each, right after ITS updates, with the current
@@ -355,8 +429,10 @@ class multi_mcmc : public slam_result_of<ControlModel, ObservationModel> {
   // of the round before.
   void ensure_baseline() {  // the log likelihoods the chains have before their first round
     if (!chain_ll.empty()) return;
+    std::uint32_t K = 0;
+    const auto rec = gather(false, &K);
     chain_ll.resize(chains);
-    detail::check(h, mcmcgpu_get_log_likelihood(h, chain_ll.data()), "mcmcgpu_get_log_likelihood");
+    for (unsigned int c = 0; c < chains; ++c) chain_ll[c] = rec[c].log_likelihood;
   }
   void compare_round(const double* after) {
     for (unsigned int c = 0; c < chains; ++c) {
@@ -375,39 +451,90 @@ class multi_mcmc : public slam_result_of<ControlModel, ObservationModel> {
              unsigned int seed, const gpu_capacity& cap = gpu_capacity(),
              const std::string& report = "multi-mcmc-report.txt")
       : data(data), chains(num_chains), mcmc_end_steps(end_steps), report_path(report) {
-    mcmcgpu_config cfg{};
-    cfg.device = cap.device;
-    cfg.max_chains = num_chains;
-    cfg.max_timesteps = cap.timesteps;
-    cfg.max_features = cap.features;
-    cfg.max_observations = cap.observations;
-    cfg.feature_uniform_first = cap.feature_uniform_first ? 1 : 0;
-    cfg.range_bearing = decltype(problem)::bearing ? 1 : 0;
-    if (num_chains <= 64) {  // split mode only pays for few chains (see completed)
-      cfg.max_split_slices = cap.split_slices;
-      split_slices = cap.split_slices;
-      split_min_observations = cap.split_min_observations;
-    }
-    if (mcmcgpu_create(&cfg, &h) != 0) throw std::runtime_error(std::string("mcmcgpu_create: ") + mcmcgpu_last_error(nullptr));
+    if (num_chains == 0) throw std::runtime_error("multi_mcmc: no chains");
+    std::vector<int> devices = cap.devices.empty() ? std::vector<int>{cap.device} : cap.devices;
+    slots = (num_chains + unsigned(devices.size()) - 1) / unsigned(devices.size());
+    devices.resize((num_chains + slots - 1) / slots);  // fewer chains than GPUs: the last ones stay idle
+    bool distinct = true;
+    for (std::size_t i = 0; i < devices.size(); ++i)
+      for (std::size_t k = 0; k < i; ++k) distinct = distinct && devices[i] != devices[k];
+    using mode = gpu_capacity::exchange_mode;
+    use_rccl = cap.exchange == mode::rccl || (cap.exchange == mode::automatic && devices.size() > 1 && distinct);
+    if (use_rccl && !distinct) throw std::runtime_error("multi_mcmc: RCCL needs every handle on a GPU of its own");
     std::vector<std::uint32_t> seeds(num_chains);
-    mcmcgpu_seed_sequence(seed, num_chains, seeds.data());  // successive draws of random_source(seed)
-    detail::check(h, mcmcgpu_init_chains(h, num_chains, seeds.data(), nullptr, 0), "mcmcgpu_init_chains");
+    mcmcgpu_seed_sequence(seed, num_chains, seeds.data());  // successive draws of random_source(seed), chain order
+    for (std::size_t g = 0; g < devices.size(); ++g) {
+      mcmcgpu_config cfg{};
+      cfg.device = devices[g];
+      cfg.max_chains = slots;
+      cfg.max_timesteps = cap.timesteps;
+      cfg.max_features = cap.features;
+      cfg.max_observations = cap.observations;
+      cfg.feature_uniform_first = cap.feature_uniform_first ? 1 : 0;
+      cfg.range_bearing = problem_type::bearing ? 1 : 0;
+      if (num_chains <= 64) {  // split mode only pays for few chains (see completed)
+        cfg.max_split_slices = cap.split_slices;
+        split_slices = cap.split_slices;
+        split_min_observations = cap.split_min_observations;
+      }
+      mcmcgpu_handle h = nullptr;
+      if (mcmcgpu_create(&cfg, &h) != 0) {
+        const std::string why = mcmcgpu_last_error(nullptr);
+        for (mcmcgpu_handle made : hs) mcmcgpu_destroy(made);
+        throw std::runtime_error("mcmcgpu_create: " + why);
+      }
+      hs.push_back(h);
+      count.push_back(std::min<unsigned int>(slots, num_chains - unsigned(g) * slots));
+      detail::check(h, mcmcgpu_init_chains(h, count[g], seeds.data() + g * slots, nullptr, 0), "mcmcgpu_init_chains");
+    }
+    sent.resize(hs.size());
+    if (use_rccl) detail::check(hs[0], mcmcgpu_comm_init_all(hs.data(), int(hs.size()), slots), "mcmcgpu_comm_init_all");
   }
-  ~multi_mcmc() { mcmcgpu_destroy(h); }
+  ~multi_mcmc() {
+    for (mcmcgpu_handle h : hs) mcmcgpu_destroy(h);
+  }
   multi_mcmc(const multi_mcmc&) = delete;
   multi_mcmc& operator=(const multi_mcmc&) = delete;
 
   unsigned int num_chains() const { return chains; }
+  unsigned int num_handles() const { return unsigned(hs.size()); }
+  bool exchanges_through_rccl() const { return use_rccl; }
   double get_log_likelihood() const { return best_ll; }
 
-  // average_slam_result over the chains (multi_mcmc.hpp:71-73): summed on the device, only the
+  // average_slam_result over the chains (multi_mcmc.hpp:71-73): summed on the devices, only the
   // averaged accumulated poses and landmark positions come back; the tree of relative poses is
-  // rebuilt from them as the reference does (average_slam_result.hpp:94-99).
+  // rebuilt from them as the reference does (average_slam_result.hpp:94-99).  Three phases over
+  // all handles: base vectors from global chain 0 to everyone, the sums of differences added up
+  // over the handles, the average.
   std::unique_ptr<slam_result_type> get_average() const {
     std::uint32_t T = 0, F = 0, C = 0;
-    detail::check(h, mcmcgpu_get_dims(h, &T, &F, &C), "mcmcgpu_get_dims");
+    detail::check(hs[0], mcmcgpu_get_dims(hs[0], &T, &F, &C), "mcmcgpu_get_dims");
     std::vector<double> cum(3 * std::size_t(T)), world(2 * std::size_t(F));
-    detail::check(h, mcmcgpu_get_average(h, cum.data(), world.data()), "mcmcgpu_get_average");
+    const std::size_t n = cum.size() + world.size();
+    if (use_rccl || hs.size() == 1) {
+      for (int phase = 0; phase < 3; ++phase) {
+        if (phase < 2) group_begin();
+        for (std::size_t g = 0; g < hs.size(); ++g)
+          detail::check(hs[g],
+                        mcmcgpu_average_collective(hs[g], phase, chains, g == 0 ? cum.data() : nullptr,
+                                                   g == 0 ? world.data() : nullptr),
+                        "mcmcgpu_average_collective");
+        if (phase < 2) group_end();
+      }
+    } else {  // handles that share a GPU: the host carries base and sums between them
+      std::vector<double> base(n), total(n, 0.0), part(n);
+      detail::check(hs[0], mcmcgpu_average_collective(hs[0], 0, chains, nullptr, nullptr), "mcmcgpu_average_collective");
+      detail::check(hs[0], mcmcgpu_average_buffer(hs[0], 0, 0, base.data()), "mcmcgpu_average_buffer");
+      for (std::size_t g = 0; g < hs.size(); ++g) {
+        if (g) detail::check(hs[g], mcmcgpu_average_buffer(hs[g], 0, 1, base.data()), "mcmcgpu_average_buffer");
+        // handle 0 leaves out the base chain itself; the others own no global chain 0
+        detail::check(hs[g], mcmcgpu_average_sum(hs[g], nullptr, g == 0 ? 0 : -1, nullptr), "mcmcgpu_average_sum");
+        detail::check(hs[g], mcmcgpu_average_buffer(hs[g], 1, 0, part.data()), "mcmcgpu_average_buffer");
+        for (std::size_t i = 0; i < n; ++i) total[i] += part[i];
+      }
+      detail::check(hs[0], mcmcgpu_average_buffer(hs[0], 1, 1, total.data()), "mcmcgpu_average_buffer");
+      detail::check(hs[0], mcmcgpu_average_collective(hs[0], 2, chains, cum.data(), world.data()), "mcmcgpu_average_collective");
+    }
     auto result = std::make_unique<slam_result_impl<state_type, feature_type>>();
     result->get_trajectory().reserve(T);
     for (std::uint32_t t = 0; t < T; ++t)
@@ -418,31 +545,37 @@ class multi_mcmc : public slam_result_of<ControlModel, ObservationModel> {
   }
 
   // `count` updates on every chain, then the arg-max (strict >, first maximum wins).
-  void update(unsigned int count) {
+  void update(unsigned int n) {
     ensure_baseline();
-    detail::check(h, mcmcgpu_run(h, count), "mcmcgpu_run");
+    for (mcmcgpu_handle h : hs) detail::check(h, mcmcgpu_run(h, n), "mcmcgpu_run");
+    std::uint32_t K = 0;
+    const auto rec = gather(false, &K);
     std::vector<double> ll(chains);
-    detail::check(h, mcmcgpu_get_log_likelihood(h, ll.data()), "mcmcgpu_get_log_likelihood");
+    for (unsigned int c = 0; c < chains; ++c) ll[c] = rec[c].log_likelihood;
     compare_round(ll.data());
   }
 
+  // The reference's multi_mcmc::timestep only forwards the timestep to its chains
+  // (multi_mcmc.hpp:77-79): the new timestep's data is appended on every handle and the chains grow.
   void timestep(timestep_type t) override {
     if (std::size_t(t) + 1 <= next_timestep) return;
     problem.absorb(*data, std::size_t(t));
-    problem.upload(h);
-    detail::check(h, mcmcgpu_grow(h, std::uint32_t(std::size_t(t))), "mcmcgpu_grow");
+    for (std::size_t g = 0; g < hs.size(); ++g) {
+      problem.append_to(hs[g], sent[g], nullptr, nullptr);
+      detail::check(hs[g], mcmcgpu_grow(hs[g], std::uint32_t(std::size_t(t))), "mcmcgpu_grow");
+    }
     next_timestep = std::size_t(t) + 1;
   }
 
   // End steps with a report line after every 100 updates (multi_mcmc.hpp:121-139).  The chains
   // run up to 256 report intervals per launch and leave one record per chain and interval behind
-  // (mcmcgpu_run_reported); the lines, and the best chain after every interval, are derived from
-  // those records exactly as the reference's round-by-round loop would have.
+  // (mcmcgpu_run_reported); the records of all handles are gathered, and the lines, and the best
+  // chain after every interval, are derived from them exactly as the reference's round-by-round
+  // loop would have.
   void completed() override {
     std::ofstream report(report_path);
     unsigned int remaining = mcmc_end_steps;
     const unsigned int report_every = 100, max_intervals = 256;
-    std::vector<mcmcgpu_chain_summary> rec;
     std::vector<double> after(chains);
     ensure_baseline();
     while (remaining > 0) {
@@ -451,14 +584,14 @@ class multi_mcmc : public slam_result_of<ControlModel, ObservationModel> {
       // few chains on a large data set leave most of the GPU idle with one workgroup each: their
       // reading streams are then cut into slices (measured on 100 000 poses: 1.5x at 16 chains,
       // 1.15x at 64, a loss from about 200 chains on)
-      if (split_slices && chains <= 64 && problem.N() >= split_min_observations)
-        detail::check(h, mcmcgpu_run_split_reported(h, n, split_slices, report_every, nullptr), "mcmcgpu_run_split_reported");
-      else
-        detail::check(h, mcmcgpu_run_reported(h, n, report_every, nullptr), "mcmcgpu_run_reported");
+      for (mcmcgpu_handle h : hs) {
+        if (split_slices && chains <= 64 && problem.N() >= split_min_observations)
+          detail::check(h, mcmcgpu_run_split_reported(h, n, split_slices, report_every, nullptr), "mcmcgpu_run_split_reported");
+        else
+          detail::check(h, mcmcgpu_run_reported(h, n, report_every, nullptr), "mcmcgpu_run_reported");
+      }
       std::uint32_t intervals = 0;
-      detail::check(h, mcmcgpu_get_reports(h, nullptr, 0, &intervals), "mcmcgpu_get_reports");
-      rec.resize(std::size_t(intervals) * chains);
-      detail::check(h, mcmcgpu_get_reports(h, rec.data(), intervals, &intervals), "mcmcgpu_get_reports");
+      const auto rec = gather(true, &intervals);
       for (std::uint32_t k = 0; k < intervals; ++k) {
         std::uint64_t u = 0, a = 0;
         for (unsigned int c = 0; c < chains; ++c) {
@@ -475,11 +608,24 @@ class multi_mcmc : public slam_result_of<ControlModel, ObservationModel> {
 
   timestep_type current_timestep() const override { return timestep_type(next_timestep == 0 ? 0 : next_timestep - 1); }
 
+  // The best chain's trajectory.  Through RCCL its owner broadcasts the packed state to every
+  // handle (what a process per GPU would do to let each rank answer); otherwise it is read from
+  // the handle that holds it.
   const trajectory_type& get_trajectory() const override {
     const std::size_t T = current_timestep();
     std::vector<double> rel(3 * T);
-    detail::check(h, mcmcgpu_get_state(h, max_likelihood, rel.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr),
-                  "mcmcgpu_get_state");
+    std::uint32_t local = 0;
+    mcmcgpu_handle owner = owner_of(max_likelihood, &local);
+    if (use_rccl) {
+      group_begin();
+      for (mcmcgpu_handle h : hs)
+        detail::check(h, mcmcgpu_broadcast_state(h, int(max_likelihood / slots), local), "mcmcgpu_broadcast_state");
+      group_end();
+      detail::check(hs[0], mcmcgpu_get_broadcast_state(hs[0], rel.data(), nullptr), "mcmcgpu_get_broadcast_state");
+    } else {
+      detail::check(owner, mcmcgpu_get_state(owner, local, rel.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr),
+                    "mcmcgpu_get_state");
+    }
     trajectory_mirror.clear();
     for (std::size_t t = 0; t < T; ++t)
       trajectory_mirror.push_back(state_type::cartesian(rel[3 * t], rel[3 * t + 1], rel[3 * t + 2]));
@@ -487,10 +633,12 @@ class multi_mcmc : public slam_result_of<ControlModel, ObservationModel> {
   }
 
   const feature_map_type& get_feature_map() const override {
+    std::uint32_t local = 0;
+    mcmcgpu_handle owner = owner_of(max_likelihood, &local);
     std::uint32_t T = 0, F = 0, C = 0;
-    detail::check(h, mcmcgpu_get_dims(h, &T, &F, &C), "mcmcgpu_get_dims");
+    detail::check(owner, mcmcgpu_get_dims(owner, &T, &F, &C), "mcmcgpu_get_dims");
     std::vector<double> world(2 * std::size_t(F));
-    detail::check(h, mcmcgpu_get_state(h, max_likelihood, nullptr, nullptr, nullptr, nullptr, world.data(), nullptr, nullptr),
+    detail::check(owner, mcmcgpu_get_state(owner, local, nullptr, nullptr, nullptr, nullptr, world.data(), nullptr, nullptr),
                   "mcmcgpu_get_state");
     map_mirror.clear();
     for (std::uint32_t f = 0; f < F; ++f)
@@ -498,7 +646,7 @@ class multi_mcmc : public slam_result_of<ControlModel, ObservationModel> {
     return map_mirror;
   }
 
-  mcmcgpu_handle native_handle() const { return h; }
+  mcmcgpu_handle native_handle(unsigned int g = 0) const { return hs.at(g); }
 };
 
 // slam_log_likelihood (src/slam/slam_likelihood.hpp:26-58) of ANY estimate -- the reference calls

@@ -274,3 +274,44 @@ def test_multi_mcmc_with_few_chains_in_split_mode_writes_the_same_report(tmp_pat
     for a, b in zip(*reports):
         assert a[0] == b[0] and a[1] == b[1]  # updates and accepts per chain
         assert abs(a[2] - b[2]) <= 1e-9 * abs(a[2])  # best log likelihood
+
+
+def _multi_mcmc_run(tmp_path, tag, *extra):
+    d = tmp_path / tag
+    d.mkdir()
+    out = subprocess.run([EXE, "--dataset", "Plaza2", "--dataset-dir", PLAZA, "--multi-mcmc", "--multi-mcmc-chains", "7",
+                          "--multi-mcmc-end-steps", "250", "--sensor-range-stddev", "4", "--seed", "7", *extra],
+                         capture_output=True, text=True, timeout=600, cwd=d)
+    assert out.returncode == 0, out.stdout + out.stderr
+    report = open(d / "multi-mcmc-report.txt").read()
+    keep = [ln for ln in out.stdout.splitlines() if ln.startswith(("Multi-MCMC-SLAM log", "Multi-MCMC-SLAM best", "Averaged"))]
+    return report, keep, out.stdout
+
+
+@pytest.mark.gpu
+def test_multi_mcmc_through_a_one_rank_rccl_communicator(tmp_path):
+    """--exchange rccl: the chain summaries, the best chain's state and the averaging sums go through
+    ncclAllGather / ncclBroadcast / ncclAllReduce of a communicator of one rank (all a one-GPU box can hold) --
+    the same report, best chain and average as without an exchange."""
+    plain = _multi_mcmc_run(tmp_path, "plain")
+    rccl = _multi_mcmc_run(tmp_path, "rccl", "--exchange", "rccl")
+    assert "exchange through RCCL" in rccl[2] and "exchange through nothing" in plain[2]
+    assert rccl[0] == plain[0] and rccl[1] == plain[1]
+
+
+@pytest.mark.gpu
+def test_multi_mcmc_sharded_over_handles_gives_the_same_run(tmp_path):
+    """7 chains as 4 + 3 on two handles (both on GPU 0, so the exchange goes through host memory; on GPUs of
+    their own the same code path uses RCCL): seeds, chain order, report lines, best chain and average are
+    those of one handle with 7 chains (src/slam/multi_mcmc.hpp:105-139, 160-166)."""
+    one = _multi_mcmc_run(tmp_path, "one")
+    two = _multi_mcmc_run(tmp_path, "two", "--devices", "0,0")
+    three = _multi_mcmc_run(tmp_path, "three", "--devices", "0,0,0")
+    assert "7 on 2 handle(s), exchange through host memory" in two[2]
+    assert "7 on 3 handle(s)" in three[2]
+    for sharded in (two, three):
+        assert sharded[0] == one[0]
+        assert sharded[1][:2] == one[1][:2]  # best log likelihood and best chain's estimate: bit for bit
+        # the average adds the per-handle partial sums in another order
+        a, b = float(sharded[1][2].split()[-1]), float(one[1][2].split()[-1])
+        assert abs(a - b) <= 1e-9 * abs(b)
