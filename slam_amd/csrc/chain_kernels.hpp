@@ -53,6 +53,10 @@ struct Dev {
   const double* osd;          // [Ncap] std deviation of a reading
   const double* oisd;         // [Ncap] 1 / std deviation
   const uint32_t* opiv;       // [Ncap/32+1] timestep of every 32nd reading (search pivots)
+  // [Fcap][tblk_stride] readings of landmark f taken before timestep b << tblk_shift, for the
+  // boundaries b = 0 .. tblk_n that the last layout of the problem covered
+  const uint32_t* tblk;
+  uint32_t tblk_shift, tblk_n, tblk_stride;
   const uint32_t* toff;       // [Tcap+2] arrivals at timestep t: tobs[toff[t] .. toff[t+1])
   const uint32_t* tobs;       // [Ncap] arrival order -> landmark-major position
   const uint32_t* ffirst;     // [Fcap] timestep of a landmark's first reading
@@ -192,6 +196,9 @@ struct Shared {
   double llc;     // control-model part of ll
   double Ws, Wf;  // weight totals, valid while !w_dirty
   int w_dirty;
+  // LDS copies of the tops of the two weight trees (advance_kernel, dynamic LDS): byte address in
+  // LDS of each copy (0 = none) and the stride 2^shift of the nodes it holds
+  uint32_t sw_top, fw_top, sw_shift, fw_shift;
   int pending, use_weight;
   double new_pll, old_pll;
   uint32_t rp_obs;
@@ -238,6 +245,15 @@ MG_DEV void append_pose(const Dev& d, uint32_t c, uint32_t Tcur, const Pose& rel
   const Pose n = compose(world_pose(d, c, Tcur), rel);
   d.pxy[i + 1] = PoseXY{n.x, n.y};
   d.pth[i + 1] = n.th;
+}
+
+// The chain's two weight trees as the driver sees them: global arrays, with their tops in LDS when
+// the kernel has set copies up (see advance_kernel).
+MG_DEV wt::Cached state_tree(const Dev& d, uint32_t c, const Shared& S) {
+  return wt::Cached{d.sw + size_t(c) * d.Tcap, S.sw_top, S.sw_shift};
+}
+MG_DEV wt::Cached landmark_tree(const Dev& d, uint32_t c, const Shared& S) {
+  return wt::Cached{d.fw + size_t(c) * d.Fcap, S.fw_top, S.fw_shift};
 }
 
 // ---------------------------------------------------------------------------
@@ -695,14 +711,28 @@ MG_DEV double eval_feature_edge(const Dev& d, uint32_t c, Shared& S, uint32_t f,
   return block_sum(acc, S);
 }
 
-// upper_bound of timestep t in the time-sorted readings [lo, hi).  The pivot
-// table (timestep of every 32nd reading) narrows the range to at most 32
-// readings first, so the search touches a few cache lines instead of
-// log2(hi - lo) scattered ones.
-MG_DEV uint32_t split_readings(const Dev& d, uint32_t lo, uint32_t hi, uint32_t t) {
+// upper_bound of timestep t in the time-sorted readings [lo, hi) of landmark f.  Two tables cut the
+// search short: per landmark, how many of its readings precede each boundary of a block of
+// 2^tblk_shift timesteps (one load of two neighbouring entries leaves the readings of one block,
+// a visit's worth, to search); and, for timesteps the table does not cover yet (data appended
+// since the last layout), the timestep of every 32nd reading, which narrows the range to at most 32
+// readings, so the search touches a few cache lines instead of log2(hi - lo) scattered ones.
+MG_DEV uint32_t split_readings(const Dev& d, uint32_t f, uint32_t lo, uint32_t hi, uint32_t t) {
   uint32_t a = lo, b = hi;
-  if (hi - lo > 64) {
-    uint32_t pa = (lo + 31) >> 5, pb = (hi + 31) >> 5;  // pivots at positions 32*i in [lo, hi)
+  if (d.tblk_n) {
+    const uint32_t* row = d.tblk + size_t(f) * d.tblk_stride;
+    const uint32_t q = t >> d.tblk_shift;
+    if (q < d.tblk_n) {
+      const uint32_t ra = lo + row[q], rb = lo + row[q + 1];
+      a = ra < hi ? ra : hi;
+      b = rb < hi ? rb : hi;
+    } else {
+      const uint32_t ra = lo + row[d.tblk_n];
+      a = ra < hi ? ra : hi;
+    }
+  }
+  if (b - a > 64) {
+    uint32_t pa = (a + 31) >> 5, pb = (b + 31) >> 5;  // pivots at positions 32*i in [a, b)
     const uint32_t pa0 = pa;
     while (pa < pb) {  // first pivot with timestep > t
       const uint32_t m = (pa + pb) >> 1;
@@ -712,7 +742,7 @@ MG_DEV uint32_t split_readings(const Dev& d, uint32_t lo, uint32_t hi, uint32_t 
         pb = m;
     }
     if (pa > pa0) a = (pa - 1) << 5;  // reading 32*(pa-1) is <= t
-    if ((pa << 5) < hi) b = pa << 5;  // reading 32*pa is > t
+    if ((pa << 5) < b) b = pa << 5;   // reading 32*pa is > t
   }
   while (a < b) {
     const uint32_t m = (a + b) >> 1;
@@ -769,7 +799,7 @@ MG_DEV double eval_state_edge(const Dev& d, uint32_t c, Shared& S, uint32_t t, c
         const uint32_t pt = d.fpt[fbase + f];
         const Vec2 e{d.fex[fbase + f], d.fey[fbase + f]};
         const Pose Pp = world_pose(d, c, pt);
-        const uint32_t a = split_readings(d, lo, hi, t);
+        const uint32_t a = split_readings(d, f, lo, hi, t);
         const Vec2 w = act(Pp, e);
         Vec2 wn;
         uint32_t slo, shi;
@@ -918,7 +948,7 @@ MG_DEV void driver_add_state_edge(const Dev& d, uint32_t c, Shared& S) {
   d.relth[ri] = est.th;
   append_pose(d, c, t, est);
   const double lp = control_log_pdf(mu, sd, est);
-  wt::push_back(d.sw + size_t(c) * d.Tcap, t, edge_weight_from_log_pdf(lp, 3.0, nullptr));
+  wt::push_back(state_tree(d, c, S), t, edge_weight_from_log_pdf(lp, 3.0, nullptr));
   S.w_dirty = 1;
   S.ll += lp;
   S.llc += lp;
@@ -930,16 +960,15 @@ MG_DEV void driver_add_state_edge(const Dev& d, uint32_t c, Shared& S) {
 // gives bit-identical values.
 MG_DEV void refresh_totals(const Dev& d, uint32_t c, Shared& S) {
   if (!S.w_dirty) return;
-  S.Ws = wt::total(d.sw + size_t(c) * d.Tcap, S.Tcur);
-  S.Wf = wt::total(d.fw + size_t(c) * d.Fcap, S.nf);
+  S.Ws = wt::total(state_tree(d, c, S), S.Tcur);
+  S.Wf = wt::total(landmark_tree(d, c, S), S.nf);
   S.w_dirty = 0;
 }
 
 // Selection and proposal of one update (mcmc_slam.hpp:339-368, :375-382).
 // Returns false when nothing can be updated (both weight totals zero, :345).
 MG_DEV bool driver_begin_update(const Dev& d, uint32_t c, Shared& S) {
-  const double* sw = d.sw + size_t(c) * d.Tcap;
-  const double* fw = d.fw + size_t(c) * d.Fcap;
+  const wt::Cached sw = state_tree(d, c, S), fw = landmark_tree(d, c, S);
   refresh_totals(d, c, S);
   const double Ws = S.Ws, Wf = S.Wf;
   if (Ws == 0 && Wf == 0) return false;
@@ -1008,8 +1037,7 @@ MG_DEV bool driver_finish_update(const Dev& d, uint32_t c, Shared& S, double obs
   // weighed by the inverse temperature; with beta = 1 this is log_ratio bit for bit
   const double tempered = is_state ? (S.new_pll - S.old_pll) + S.beta * obs_ratio : S.beta * obs_ratio;
   double accept_log_ratio = tempered - proposal_log_ratio;
-  double* sw = d.sw + size_t(c) * d.Tcap;
-  double* fw = d.fw + size_t(c) * d.Fcap;
+  const wt::Cached sw = state_tree(d, c, S), fw = landmark_tree(d, c, S);
   if (S.use_weight) {
     double old_log_weight;
     const double old_weight = edge_weight_from_log_pdf(S.old_pll, dim, &old_log_weight);
@@ -1063,8 +1091,7 @@ MG_DEV bool driver_arrival(const Dev& d, uint32_t c, Shared& S, uint32_t o) {
     d.fcnt[fi] = 1;
     d.fpt[fi] = t;
     d.flast[fi] = t;
-    wt::push_back(d.fw + size_t(c) * d.Fcap, f,
-                  edge_weight_from_log_pdf(reading_proposal_log_pdf(m, est), 2.0, nullptr));
+    wt::push_back(landmark_tree(d, c, S), f, edge_weight_from_log_pdf(reading_proposal_log_pdf(m, est), 2.0, nullptr));
     S.w_dirty = 1;
     S.ll += reading_log_pdf(m, est);
     S.nf = f + 1;
@@ -1200,6 +1227,8 @@ MG_DEV void chain_state_load(const Dev& d, uint32_t c, Shared& S) {
     S.n_moved = 0;
     S.failed = 0;
     S.w_dirty = 1;
+    S.sw_top = S.fw_top = 0;
+    S.sw_shift = S.fw_shift = 0;
     S.pending = PEND_NONE;
     for (int i = 0; i < 8; ++i) S.phase[i] = 0;
   }
@@ -1265,7 +1294,7 @@ MG_PIECE void piece_finish_update(DevArgs dp, SharedLds sp, uint32_t c, uint32_t
   } else if (!accept) {  // rejected re-parenting update: reset the edge weight, :321-322
     const uint32_t o = S.rp_obs;
     const size_t fi = size_t(c) * d.Fcap + idx;
-    wt::set(d.fw + size_t(c) * d.Fcap, S.nf, idx,
+    wt::set(landmark_tree(d, c, S), S.nf, idx,
             edge_weight_from_log_pdf(reading_proposal_log_pdf(load_reading(d, o), Vec2{d.fex[fi], d.fey[fi]}), 2.0,
                                      nullptr));
     S.w_dirty = 1;
@@ -1290,15 +1319,31 @@ MG_PIECE void piece_commit(DevArgs dp, SharedLds sp, uint32_t c, uint32_t idx, d
 // grid = chains, block = threads_per_chain.  first_tn = the next timestep the
 // chains have not processed yet; Tcur0 = state edges grown so far.  `d` must
 // stay the first parameter: the pieces read it through the argument block.
+// What the launch sets aside in dynamic LDS for copies of the weight trees' tops: sw_n / fw_n nodes
+// (0 = no copy) at strides 2^sw_shift / 2^fw_shift; the state tree's copy comes first.
+struct TreeTops {
+  uint32_t sw_n, sw_shift, fw_n, fw_shift;
+};
 __global__ void advance_kernel(Dev d, uint32_t first_tn, uint32_t Tcur0, uint32_t upto, uint32_t steps_per_ts,
-                               uint32_t end_steps, uint32_t grow) {
+                               uint32_t end_steps, uint32_t grow, TreeTops tops) {
   __shared__ Shared S;
+  extern __shared__ double tree_tops[];
   const DevArgs dp = (DevArgs)__builtin_amdgcn_kernarg_segment_ptr();
   const SharedLds sp = (SharedLds)&S;
   const uint32_t c = blockIdx.x;
   const bool bearings = d.obear != nullptr;
   chain_state_load(d, c, S);
+  {  // nodes beyond a tree's current size hold nothing yet; they are written (through) before they are read
+    const double* sw = d.sw + size_t(c) * d.Tcap;
+    const double* fw = d.fw + size_t(c) * d.Fcap;
+    for (uint32_t j = threadIdx.x; j < tops.sw_n; j += blockDim.x) tree_tops[j] = sw[size_t(j) << tops.sw_shift];
+    for (uint32_t j = threadIdx.x; j < tops.fw_n; j += blockDim.x) tree_tops[tops.sw_n + j] = fw[size_t(j) << tops.fw_shift];
+  }
   if (threadIdx.x == 0) {
+    S.sw_top = tops.sw_n ? uint32_t(uintptr_t((wt::LdsDoubles)&tree_tops[0])) : 0;
+    S.fw_top = tops.fw_n ? uint32_t(uintptr_t((wt::LdsDoubles)&tree_tops[tops.sw_n])) : 0;
+    S.sw_shift = tops.sw_shift;
+    S.fw_shift = tops.fw_shift;
     S.Tcur = Tcur0;
     S.tn = first_tn;
     S.upto = upto;
@@ -1485,7 +1530,7 @@ MG_DEV uint32_t split_setup_landmark(const Dev& d, uint32_t c, uint32_t f, const
       const Pose q{k.q[0], k.q[1], k.q[2]};
       const Pose Pt = world_pose(d, c, t), Pt1 = world_pose(d, c, t + 1);
       const uint32_t lo = d.foff[f], hi = lo + d.fcnt[fi], pt = d.fpt[fi];
-      const uint32_t a = split_readings(d, lo, hi, t);
+      const uint32_t a = split_readings(d, f, lo, hi, t);
       w = act(world_pose(d, c, pt), Vec2{d.fex[fi], d.fey[fi]});
       if (t < pt) {
         wn = act(Pt, act(q, act_inverse(Pt1, w)));
@@ -1749,7 +1794,7 @@ __global__ void commit_kernel(Dev d, uint32_t c, int kind, uint32_t idx, double 
       d.relx[ri] = q.x;
       d.rely[ri] = q.y;
       d.relth[ri] = q.th;
-      wt::set(d.sw + size_t(c) * d.Tcap, Tcur, idx, new_weight);
+      wt::set(wt::Plain{d.sw + size_t(c) * d.Tcap}, Tcur, idx, new_weight);
       d.ll[c] += log_ratio;
       d.llc[c] += control_part;
     }
@@ -1757,7 +1802,7 @@ __global__ void commit_kernel(Dev d, uint32_t c, int kind, uint32_t idx, double 
     const size_t fi = size_t(c) * d.Fcap + idx;
     d.fex[fi] = q0;
     d.fey[fi] = q1;
-    wt::set(d.fw + size_t(c) * d.Fcap, d.nf[c], idx, new_weight);
+    wt::set(wt::Plain{d.fw + size_t(c) * d.Fcap}, d.nf[c], idx, new_weight);
     d.ll[c] += log_ratio;
   }
 }
@@ -1846,9 +1891,9 @@ __global__ void readout_kernel(Dev d, uint32_t c, uint32_t Tcur, double* feat_wo
     const Vec2 w = act(world_pose(d, c, d.fpt[fi]), Vec2{d.fex[fi], d.fey[fi]});
     feat_world[2 * size_t(i)] = w.x;
     feat_world[2 * size_t(i) + 1] = w.y;
-    feat_w[i] = wt::get(d.fw + size_t(c) * d.Fcap, i);
+    feat_w[i] = wt::get(wt::Plain{d.fw + size_t(c) * d.Fcap}, i);
   }
-  if (i < Tcur) state_w[i] = wt::get(d.sw + size_t(c) * d.Tcap, i);
+  if (i < Tcur) state_w[i] = wt::get(wt::Plain{d.sw + size_t(c) * d.Tcap}, i);
 }
 
 // One chain's estimate packed for a hand-off to the host: relative poses [Tcur][3], world landmark
@@ -2124,7 +2169,7 @@ MG_DEV void build_tree_levels(double* node, uint32_t n) {
   for (uint32_t low = 2; low < n; low <<= 1) {
     __syncthreads();
     for (uint32_t i = low * (2 * threadIdx.x + 1); i < n; i += 2 * low * blockDim.x)
-      node[i] = wt::sum_to_ancestor(node, i - 1, wt::parent(i)) + node[i];
+      node[i] = wt::sum_to_ancestor(wt::Plain{node}, i - 1, wt::parent(i)) + node[i];
   }
   __syncthreads();
 }

@@ -180,48 +180,99 @@ MG_DEV uint32_t suffix_mask(uint32_t i) {
 }
 MG_DEV uint32_t child_containing(uint32_t p, uint32_t i) { return i & ~(suffix_mask(p ^ i) >> 1); }
 
-MG_DEV double sum_to_ancestor(const double* node, uint32_t i, uint32_t ancestor) {
+// Where a tree's nodes live.  Plain: an array in global memory.  Cached: the same array, with a copy
+// in LDS of every node whose index is a multiple of 2^shift -- the nodes a descent probes first
+// and a point update rewrites last -- kept current by writing through.  Both hand out the same
+// values, so the arithmetic (and with it every searched index) does not depend on the choice.
+struct Plain {
+  double* g;
+  MG_DEV double ld(uint32_t i) const { return g[i]; }
+  MG_DEV void st(uint32_t i, double v) const { g[i] = v; }
+  MG_DEV void warm(uint32_t, uint32_t, uint32_t) const {}
+};
+using LdsDoubles = __attribute__((address_space(3))) double*;
+struct Cached {
+  double* g;
+  uint32_t top;  // LDS byte address of the copy; 0: no copy (LDS address 0 belongs to static data)
+  uint32_t shift;
+  MG_DEV LdsDoubles lds() const { return (LdsDoubles)(uintptr_t)top; }
+  MG_DEV bool held(uint32_t i) const { return top && (i & ((1u << shift) - 1u)) == 0; }
+  MG_DEV double ld(uint32_t i) const { return held(i) ? lds()[i >> shift] : g[i]; }
+  MG_DEV void st(uint32_t i, double v) const {
+    g[i] = v;
+    if (held(i)) lds()[i >> shift] = v;
+  }
+  // A descent has narrowed its range to [lo, hi) and is about to probe `mid`, which is not held in
+  // LDS: every node it can still probe lies in the 2^shift nodes from lo on.  Their cache lines
+  // (16 nodes each) are requested together, so the dependent probes that follow find them near.
+  MG_DEV void warm(uint32_t lo, uint32_t n, uint32_t mid) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (!top || shift < 5 || mid - lo != (1u << (shift - 1)) || (lo & ((1u << shift) - 1u)) != 0) return;
+    double sum = 0.0;
+    for (uint32_t j = 16; j < (1u << shift); j += 16)
+      if (lo + j < n) sum += g[lo + j];
+    asm volatile("" ::"v"(sum));
+#endif
+  }
+};
+
+template <class N>
+MG_DEV double sum_to_ancestor(const N& node, uint32_t i, uint32_t ancestor) {
   double result = 0.0;
-  for (; i != ancestor; i = parent(i)) result = node[i] + result;
+  for (; i != ancestor; i = parent(i)) result = node.ld(i) + result;
   return result;
 }
-MG_DEV double total(const double* node, uint32_t n) {
+template <class N>
+MG_DEV double total(const N& node, uint32_t n) {
   if (n == 0) return 0.0;
-  return node[0] + sum_to_ancestor(node, n - 1, 0);
+  return node.ld(0) + sum_to_ancestor(node, n - 1, 0);
 }
-MG_DEV double node_value_for(const double* node, uint32_t i, double v) {
+template <class N>
+MG_DEV double node_value_for(const N& node, uint32_t i, double v) {
   if (i == 0) return v;
   return sum_to_ancestor(node, i - 1, parent(i)) + v;
 }
-MG_DEV double get(const double* node, uint32_t i) {
-  if (i == 0) return node[0];
-  return -sum_to_ancestor(node, i - 1, parent(i)) + node[i];
+template <class N>
+MG_DEV double get(const N& node, uint32_t i) {
+  if (i == 0) return node.ld(0);
+  return -sum_to_ancestor(node, i - 1, parent(i)) + node.ld(i);
 }
-MG_DEV void push_back(double* node, uint32_t n, double v) { node[n] = node_value_for(node, n, v); }
-MG_DEV void set(double* node, uint32_t n, uint32_t i, double v) {
+template <class N>
+MG_DEV void push_back(const N& node, uint32_t n, double v) {
+  node.st(n, node_value_for(node, n, v));
+}
+template <class N>
+MG_DEV void set(const N& node, uint32_t n, uint32_t i, double v) {
   double new_value = node_value_for(node, i, v);
   if (i > 0)
     for (uint32_t next; (next = next_sibling(i)) < n; i = next) {
-      double delta = new_value + (-node[i]);
-      node[i] = new_value;
+      const double old = node.ld(i);
+      double delta = new_value + (-old);
+      node.st(i, new_value);
       const uint32_t next_parent = parent(next);
-      while ((i = parent(i)) != next_parent) delta = node[i] + delta + (-node[i]);
-      new_value = delta + node[next];
+      while ((i = parent(i)) != next_parent) {
+        const double a = node.ld(i);
+        delta = a + delta + (-a);
+      }
+      new_value = delta + node.ld(next);
     }
-  node[i] = new_value;
+  node.st(i, new_value);
 }
 // index k with prefix(k) <= value < prefix(k+1); may return n when value >= total
-MG_DEV uint32_t search(const double* node, uint32_t n, double value) {
-  if (n == 0 || value < node[0]) return 0;
+template <class N>
+MG_DEV uint32_t search(const N& node, uint32_t n, double value) {
+  if (n == 0 || value < node.ld(0)) return 0;
   uint32_t lo = 0, hi = n;
-  double origin = node[0];
+  double origin = node.ld(0);
   while (lo + 1 < hi) {
     const uint32_t mid = child_containing(lo, hi - 1);
-    if (value < origin + node[mid])
+    node.warm(lo, n, mid);
+    const double at_mid = node.ld(mid);
+    if (value < origin + at_mid)
       hi = mid;
     else {
       lo = mid;
-      origin += node[lo];
+      origin += at_mid;
     }
   }
   return hi;

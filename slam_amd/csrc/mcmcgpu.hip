@@ -39,6 +39,7 @@ struct mcmcgpu_ctx {
   double* scratch = nullptr;  // readout staging: max(3*(Tcap+1), ...) doubles
   size_t scratch_doubles = 0;
   uint32_t nthreads = 256;
+  size_t advance_lds_allowed = 48 * 1024;  // dynamic LDS advance_kernel may be launched with so far
   // host-side bookkeeping
   uint32_t chains = 0;
   bool problem_loaded = false;
@@ -123,6 +124,7 @@ int dev_alloc(mcmcgpu_handle h, T** out, size_t count) {
 uint32_t edges_grown(const mcmcgpu_ctx* h) { return h->next_timestep == 0 ? 0 : h->next_timestep - 1; }
 
 constexpr uint32_t kDeferCommitPoses = 200000;  // split mode: trajectories from here on get split_commit_kernel
+constexpr uint32_t kTimeBlockShift = 8;  // timesteps per block of the per-landmark split table: 256
 constexpr uint32_t kMaxOwnReports = 256;  // intervals of one launch the library can hold itself
 
 bool is_pow2(uint32_t v) { return v && !(v & (v - 1)); }
@@ -260,6 +262,20 @@ int lay_out(mcmcgpu_handle h, bool with_slack) {
   }
   for (uint32_t t = 0; t <= T; ++t) toff[t + 1] += toff[t];
   for (size_t i = 0; 32 * i < S; ++i) opiv[i] = h->h_ot[32 * i];
+  // per landmark: readings before each block boundary b << shift, b = 0 .. nb, where the last boundary
+  // is not beyond T + 1 (readings appended later are all at or past it, so the counts stay true)
+  const uint32_t nb = (T + 1) >> d.tblk_shift;
+  std::vector<uint32_t> tblk(size_t(F) * d.tblk_stride, 0);
+  for (uint32_t f = 0; f < F; ++f) {
+    uint32_t* row = tblk.data() + size_t(f) * d.tblk_stride;
+    uint32_t seen = 0;
+    const uint32_t first = h->f_start[f], count = h->f_count[f];
+    for (uint32_t bnd = 0; bnd <= nb; ++bnd) {
+      while (seen < count && h->h_ot[first + seen] < (bnd << d.tblk_shift)) ++seen;
+      row[bnd] = seen;
+    }
+  }
+  HIP_TRY(h, up(d.tblk, tblk.data(), tblk.size() * sizeof(uint32_t)));
   HIP_TRY(h, up(d.foff, h->f_start.data(), h->f_start.size() * sizeof(uint32_t)));
   HIP_TRY(h, up(d.toff, toff.data(), toff.size() * sizeof(uint32_t)));
   HIP_TRY(h, up(d.orec, orec.data(), size_t(S) * sizeof(ObsRec)));
@@ -290,6 +306,7 @@ int lay_out(mcmcgpu_handle h, bool with_slack) {
   d.T = T;
   d.N = N;
   d.F = F;
+  d.tblk_n = nb;
   h->sigma_all = uniform_sigma ? h->a_sd[0] : 0.0;
   d.usig_inv = uniform_sigma ? 1.0 / h->a_sd[0] : 0.0;
   h->bsigma_all = uniform_bsigma ? h->a_bsd[0] : 0.0;
@@ -326,6 +343,38 @@ hipError_t static_scratch_on(int device, void** out) {
   }
   *out = g_static_scratch[device];
   return hipSuccess;
+}
+
+// LDS of a CU and what advance_kernel declares statically (its Shared block, rounded up).
+constexpr size_t kLdsPerCu = 160 * 1024, kAdvanceStaticLds = 18 * 1024;
+static_assert(sizeof(Shared) <= kAdvanceStaticLds, "advance_kernel's static LDS outgrew its allowance");
+
+// Copies of the weight trees' tops for one launch of advance_kernel: every node whose index is a
+// multiple of 2^shift, with the smallest shifts whose copies fit into the LDS left beside the
+// workgroups that share a CU (as many as the chain count and the kernel's 128 registers allow).
+// One chain alone on a CU keeps a Plaza-sized tree whole; 1024 chains of 100 000 poses keep every
+// 64th node of the state tree and the whole landmark tree.
+TreeTops plan_tree_tops(const mcmcgpu_ctx* h, uint32_t state_tree_size) {
+  const uint32_t waves = h->nthreads / 64;
+  const uint32_t by_registers = std::max<uint32_t>(1, 16 / waves);  // 4 wavefronts per SIMD at 128 registers
+  const uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(by_registers, (h->chains + 255) / 256));
+  const size_t budget = (kLdsPerCu / per_cu - kAdvanceStaticLds - 512) / sizeof(double);  // doubles per workgroup
+  TreeTops t{0, 0, 0, 0};
+  const uint32_t F = std::max<uint32_t>(h->d.F, 1);
+  uint32_t fs = 0;
+  while (fs < 12 && size_t(F >> fs) + 1 > budget / 3) ++fs;
+  if (size_t(F >> fs) + 1 <= budget / 3) {
+    t.fw_shift = fs;
+    t.fw_n = (F >> fs) + 1;
+  }
+  const size_t left = budget - t.fw_n;
+  uint32_t ss = 0;
+  while (ss < 12 && size_t(state_tree_size >> ss) + 1 > left) ++ss;
+  if (size_t(state_tree_size >> ss) + 1 <= left) {
+    t.sw_shift = ss;
+    t.sw_n = (state_tree_size >> ss) + 1;
+  }
+  return t;
 }
 
 // How a rebuild of `chains` pose tables of n relative poses each is cut into workgroups: whole
@@ -503,6 +552,10 @@ int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out) {
   ALLOC(d.orec, d.Ncap);
   ALLOC(d.oisd, d.Ncap);
   ALLOC(d.opiv, size_t(d.Ncap) / 32 + 2);
+  d.tblk_shift = kTimeBlockShift;
+  d.tblk_stride = (d.Tcap >> kTimeBlockShift) + 3;
+  d.tblk_n = 0;
+  ALLOC(d.tblk, size_t(d.Fcap) * d.tblk_stride);
   ALLOC(d.osd, d.Ncap);
   if (cfg->range_bearing) {
     ALLOC(d.obear, d.Ncap);
@@ -883,10 +936,19 @@ int mcmcgpu_advance(mcmcgpu_handle h, uint32_t upto, uint32_t steps_per_timestep
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   const bool grow = upto + 1 > h->next_timestep;
   if (!grow && end_steps == 0) return 0;
+  // LDS copies of the tops of the weight trees: as many nodes as fit beside the workgroups that share a CU
+  const uint32_t tree_size = std::max(upto, edges_grown(h)) + 1;
+  const TreeTops tops = plan_tree_tops(h, tree_size);
+  const size_t dyn_lds = (size_t(tops.sw_n) + tops.fw_n) * sizeof(double);
+  if (dyn_lds > h->advance_lds_allowed) {
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(advance_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   int(kLdsPerCu - kAdvanceStaticLds)));
+    h->advance_lds_allowed = kLdsPerCu - kAdvanceStaticLds;
+  }
   EventPair ev;
   if (int rc = begin_timed(h, &ev)) return rc;
-  hipLaunchKernelGGL(advance_kernel, dim3(h->chains), dim3(h->nthreads), 0, h->stream, h->d, h->next_timestep,
-                     edges_grown(h), upto, steps_per_timestep, end_steps, grow ? 1u : 0u);
+  hipLaunchKernelGGL(advance_kernel, dim3(h->chains), dim3(h->nthreads), dyn_lds, h->stream, h->d, h->next_timestep,
+                     edges_grown(h), upto, steps_per_timestep, end_steps, grow ? 1u : 0u, tops);
   if (int rc = end_timed(h, ev, hipGetLastError(), "advance_kernel")) return rc;
   if (grow) h->next_timestep = upto + 1;
   return 0;
