@@ -42,10 +42,14 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=["chains", "tempering", "range-bearing"], default="chains",
+    ap.add_argument("--workload", choices=["chains", "tempering", "range-bearing", "commit-heavy"], default="chains",
                     help="chains: the headline workload; tempering: one ladder of "
                          "tempered replicas per GPU on a 1M-pose trajectory with a replica exchange after every launch; "
-                         "range-bearing: the headline workload with the reference's other observation model (48 B per unit)")
+                         "range-bearing: the headline workload with the reference's other observation model (48 B per unit); "
+                         "commit-heavy: 10 000 poses with few, noisy readings per pose (2 nearest landmarks, sigma 3 m), "
+                         "the regime of the Plaza logs: an eighth of the proposals is accepted and every accepted state "
+                         "edge re-positions all later poses, a quarter of the algorithmic bytes")
+    ap.add_argument("--range-stddev", type=float, default=None, help="sigma of the range readings, m (1; commit-heavy: 3)")
     ap.add_argument("--bearing-stddev", type=float, default=0.05, help="range-bearing: sigma of the bearings, rad")
     ap.add_argument("--chains", type=int, default=None, help="chains per GPU (1024; tempering: 64)")
     ap.add_argument("--total-chains", type=int, default=0,
@@ -58,7 +62,7 @@ def parse_args():
     ap.add_argument("--timesteps", type=int, default=None, help="poses (100 000; tempering: 1 000 000)")
     ap.add_argument("--beta-min", type=float, default=0.01, help="tempering: coldest..hottest = 1..beta_min, geometric")
     ap.add_argument("--landmarks", type=int, default=1000)
-    ap.add_argument("--k-nearest", type=int, default=10)
+    ap.add_argument("--k-nearest", type=int, default=None, help="landmarks ranged per timestep (10; commit-heavy: 2)")
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--rebuild-every", type=int, default=1, help="steps between cumulative-pose rebuilds")
     ap.add_argument("--threads-per-chain", type=int, default=0)
@@ -73,12 +77,19 @@ def parse_args():
                          "device); exercises the N > 1 code path on a one-GPU box, its numbers mean nothing")
     args = ap.parse_args()
     tempering = args.workload == "tempering"
+    heavy = args.workload == "commit-heavy"
+    if args.k_nearest is None:
+        args.k_nearest = 2 if heavy else 10
+    if args.range_stddev is None:
+        args.range_stddev = 3.0 if heavy else 1.0
+    if heavy:
+        args.no_cpu_baseline = args.no_plaza = True
     if args.chains is None:
         args.chains = 64 if tempering else 1024
     if args.updates_per_step is None:
         args.updates_per_step = 200 if tempering else 1000
     if args.timesteps is None:
-        args.timesteps = 1_000_000 if tempering else 100_000
+        args.timesteps = 1_000_000 if tempering else 10_000 if heavy else 100_000
     if args.workload == "range-bearing":
         args.no_cpu_baseline = args.no_plaza = True
     if tempering:
@@ -86,6 +97,15 @@ def parse_args():
             args.threads_per_chain = 1024  # few, long chains: the widest workgroup per chain
         args.no_cpu_baseline = args.no_plaza = True
     return args
+
+
+def library_sha16():
+    """Identifies the build of the library that is running (profiles quote it)."""
+    import hashlib
+
+    from slam_amd import capi
+    with open(capi._LIB_PATH, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
 def cpu_baseline(problem, seed, target_seconds, all_seeds=None):
@@ -232,7 +252,7 @@ def main():
     tempering = args.workload == "tempering"
     bearing = args.workload == "range-bearing"
     problem = synthetic.make_problem(T=args.timesteps, n_landmarks=args.landmarks, k_nearest=args.k_nearest,
-                                     seed=args.seed, max_tries=2 if tempering else 8,
+                                     seed=args.seed, max_tries=2 if tempering else 8, range_stddev=args.range_stddev,
                                      bearing_stddev=args.bearing_stddev if bearing else None)
     if args.total_chains:
         if args.total_chains % world:
@@ -290,7 +310,8 @@ def main():
         one_step(i)
         note(f"warm-up step {i} done")
     barrier()
-    g.kernel_time()  # reset the library's kernel timer
+    g.kernel_time()  # reset the library's kernel timers
+    g.rebuild_time()
     u0 = g.counters()
     s0 = g.traffic_counters()
     barrier()
@@ -308,6 +329,7 @@ def main():
     parallel.broadcast_from_owner(packed, owner, world)
     torch.cuda.synchronize(dev)
     kern_ms, launches = g.kernel_time()
+    rebuild_ms, rebuilds = g.rebuild_time()
     u1 = g.counters()
     s1 = g.traffic_counters()
     d_updates = int((u1[0] - u0[0]).sum())
@@ -325,23 +347,51 @@ def main():
 
     workload_name = ("synthetic planar robot: %d poses, %d landmarks, %d range readings, %d %s per GPU" %
                      (T, F, N, C, "tempered replicas (one ladder)" if tempering else
-                      "chains, range-and-bearing readings" if bearing else "chains"))
+                      "chains, range-and-bearing readings" if bearing else
+                      "chains, commit-heavy (%d nearest, sigma %g m)" % (args.k_nearest, args.range_stddev)
+                      if args.workload == "commit-heavy" else "chains"))
     if rank == 0:
-        traffic = None  # PMC counters cannot be read from inside this process: the last profiling round's figure
+        # HBM-side bytes per launch cannot be read from inside this process (they come from rocprofv3 --pmc
+        # passes over this very command, tools/profile_round.sh): the record of the last profiling round is
+        # quoted, and only if it was taken on the library that is running now
+        traffic, traffic_source = None, None
+        running_sha = library_sha16()
         import glob
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "hbm_traffic*.json"))):
             try:
                 with open(path) as f:
                     rec = json.load(f)
-                if rec["updates_per_step"] == args.updates_per_step and rec["workload"] == workload_name:
+                if rec["updates_per_step"] != args.updates_per_step or rec["workload"] != workload_name:
+                    continue
+                traffic_source = {"file": os.path.relpath(path, ROOT), "date": rec.get("date"), "commit": rec.get("commit"),
+                                  "library_sha16": rec.get("library_sha16"), "running_library_sha16": running_sha,
+                                  "counters": "2 x FETCH_SIZE + WRITE_SIZE (gfx950 tallies a wide read at half its bytes); "
+                                              "requests leaving L2, Infinity-Cache hits included"}
+                if rec.get("library_sha16") == running_sha:
                     traffic = rec["traffic_bytes_per_launch"]
+                else:
+                    traffic_source["withheld"] = "the profile was taken on another build of the library"
             except (OSError, ValueError, KeyError):
                 pass
         # a range-and-bearing reading also needs the pose's angle and the measured bearing: 48 bytes
         unit_bytes = BYTES_PER_UNIT + 16 if bearing else BYTES_PER_UNIT
-        bytes_per_launch = (d_units * unit_bytes + d_state * F * BYTES_PER_LANDMARK +
-                            d_moved * BYTES_PER_MOVED_POSE) / max(launches, 1)
+        commit_bytes = d_moved * BYTES_PER_MOVED_POSE / max(launches, 1)
+        bytes_per_launch = (d_units * unit_bytes + d_state * F * BYTES_PER_LANDMARK) / max(launches, 1) + commit_bytes
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        scan_bytes = 48.0 * T * C  # a rebuild reads 24 B and writes 24 B per pose
+        other_kernels = [{
+            "kernel": "commit_state_edge (inside advance_kernel; split_commit_kernel in split mode)",
+            "moved_poses_per_launch": d_moved / max(launches, 1),
+            "bytes_per_launch": commit_bytes,
+            "share_of_algorithmic_bytes": commit_bytes / bytes_per_launch if bytes_per_launch else 0.0,
+            "note": "48 B per re-positioned pose; no duration of its own inside the persistent kernel",
+        }]
+        if rebuilds:
+            other_kernels.append({
+                "kernel": "scan_chain_kernel (mcmcgpu_rebuild)", "ms": rebuild_ms, "launches": rebuilds,
+                "bytes_per_launch": scan_bytes, "achieved": scan_bytes / (rebuild_ms * 1e-3) / 1e9 if rebuild_ms > 0 else 0.0,
+                "frac": scan_bytes / (rebuild_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if rebuild_ms > 0 else 0.0,
+            })
         out = {
             "metric": "MCMC proposals*observations/sec (node) on 100k-pose synthetic",
             "value": units_total / elapsed_max,
@@ -363,6 +413,8 @@ def main():
                 "split_slices": args.split_slices,
                 "parallelism": "chains sharded %dx%d, per-interval summaries all-gathered every step" % (world, C),
                 "start_state": "generating trajectory and landmark positions (mcmcgpu_load_state)",
+                "range_stddev": args.range_stddev,
+                "k_nearest": args.k_nearest,
             },
             "roofline": {
                 "bound": "hbm",
@@ -370,7 +422,15 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
+                "basis": "ALGORITHMIC bytes (32 B per proposal*observation + per-proposal landmark table + 48 B per "
+                         "re-positioned pose) over the kernel's device time: the 16-byte reading records are shared by "
+                         "all chains and largely served from L2 / Infinity Cache, so this fraction can exceed what "
+                         "HBM itself delivers -- hbm_frac is the counter-based figure",
                 "traffic": traffic,
+                "hbm_frac": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and kern_ms > 0 else None,
+                "cache_served_bytes_per_launch": (bytes_per_launch - traffic) if traffic else None,
+                "traffic_source": traffic_source,
+                "other_kernels": other_kernels,
                 "kernel": "split_* kernel sequence of one step" if args.split_slices else "advance_kernel",
                 "kernel_ms": kern_ms,
                 "launches": launches,

@@ -113,8 +113,9 @@ int mcmcgpu_upload_problem(mcmcgpu_handle h, uint32_t T, const double* ctrl_mean
  * init_state_rel (3 doubles) and init_feat_rel (2 doubles per landmark that is NEW in this call,
  * in order of appearance) continue the arrays of mcmcgpu_set_initial_estimates when they reach
  * exactly up to the new edge / landmark; NULL = none.  The readings go into free slots next to
- * their landmark's list; when a list is full the library lays the problem out again with twice
- * the room (amortised O(1) per reading).  Follow with mcmcgpu_grow / mcmcgpu_advance. */
+ * their landmark's list; a landmark whose slots are used up is moved, alone, to a region of twice
+ * the size (amortised O(1) per reading); only when the slot space itself runs out is the whole
+ * problem laid out again.  Follow with mcmcgpu_grow / mcmcgpu_advance. */
 int mcmcgpu_append_timestep(mcmcgpu_handle h, const double* ctrl_mean, const double* ctrl_stddev, uint32_t n_obs,
                             const uint32_t* obs_feature, const double* obs_mean, const double* obs_stddev,
                             const double* bearing_mean, const double* bearing_stddev, const double* init_state_rel,
@@ -409,6 +410,8 @@ int mcmcgpu_sync(mcmcgpu_handle h);
 /* Average device duration (ms) of the advance kernel launches timed with HIP
  * events since the last call (reset on read), and how many there were. */
 int mcmcgpu_kernel_time(mcmcgpu_handle h, double* avg_ms, uint32_t* launches);
+/* The same for the scan kernels of mcmcgpu_rebuild calls (one rebuild = one timed launch). */
+int mcmcgpu_rebuild_time(mcmcgpu_handle h, double* avg_ms, uint32_t* launches);
 
 /* Host helpers for seeding, same generator as the chains: n successive 32-bit
  * draws of random_source(seed) -- the chain seeds of multi_mcmc

@@ -103,6 +103,7 @@ EXPORTS = [
     "mcmcgpu_load_state",
     "mcmcgpu_sync",
     "mcmcgpu_kernel_time",
+    "mcmcgpu_rebuild_time",
     "mcmcgpu_seed_sequence",
     "mcmcgpu_uniform_sequence",
     "mcmcgpu_debug_phase_cycles",
@@ -518,4 +519,9 @@ class McmcGpu:
     def kernel_time(self):
         ms, n = ctypes.c_double(), ctypes.c_uint32()
         self._check(self.lib.mcmcgpu_kernel_time(self.h, ctypes.byref(ms), ctypes.byref(n)), "mcmcgpu_kernel_time")
+        return ms.value, n.value
+
+    def rebuild_time(self):
+        ms, n = ctypes.c_double(), ctypes.c_uint32()
+        self._check(self.lib.mcmcgpu_rebuild_time(self.h, ctypes.byref(ms), ctypes.byref(n)), "mcmcgpu_rebuild_time")
         return ms.value, n.value

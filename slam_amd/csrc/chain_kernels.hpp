@@ -2020,6 +2020,31 @@ __global__ void append_kernel(Dev d, AppendArgs a) {
   }
 }
 
+// One landmark's list of `count` readings moved from slot `from` to slot `to` (a free region: the
+// two do not overlap): records, deviations, pivots of the new region, the landmark's start, and
+// the arrival index, in which every moved reading is looked up among the arrivals of its timestep.
+__global__ void move_list_kernel(Dev d, uint32_t f, uint32_t from, uint32_t to, uint32_t count) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+    const ObsRec r = d.orec[from + i];
+    const uint32_t s = to + i;
+    const_cast<ObsRec*>(d.orec)[s] = r;
+    const_cast<double*>(d.osd)[s] = d.osd[from + i];
+    const_cast<double*>(d.oisd)[s] = d.oisd[from + i];
+    if (d.obear) {
+      const_cast<double*>(d.obear)[s] = d.obear[from + i];
+      const_cast<double*>(d.obsd)[s] = d.obsd[from + i];
+      const_cast<double*>(d.obisd)[s] = d.obisd[from + i];
+    }
+    if ((s & 31u) == 0) const_cast<uint32_t*>(d.opiv)[s >> 5] = r.t;
+    for (uint32_t a = d.toff[r.t]; a < d.toff[r.t + 1]; ++a)
+      if (d.tobs[a] == from + i) {
+        const_cast<uint32_t*>(d.tobs)[a] = s;
+        break;
+      }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) const_cast<uint32_t*>(d.foff)[f] = to;
+}
+
 __global__ void init_chains_kernel(Dev d, const uint32_t* seeds) {
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= d.C) return;

@@ -24,6 +24,7 @@ thread_local std::string g_create_error;
 
 struct EventPair {
   hipEvent_t start, stop;
+  int kind;  // 0 = the update launches (advance kernel or a split-mode sequence), 1 = a pose-table rebuild
 };
 
 }  // namespace
@@ -55,13 +56,14 @@ struct mcmcgpu_ctx {
   std::vector<uint32_t> f_start, f_count, f_cap;
   uint32_t slots_used = 0;
   std::vector<uint32_t> h_tobs;  // arrival order -> slot
+  std::vector<std::vector<uint32_t>> f_arrivals;  // landmark -> arrival indices of its readings, in time order
   std::vector<uint32_t> h_ot;    // slot -> timestep (filled slots)
   std::vector<double> h_omu;     // slot -> measured range
   double sigma_all = 0.0, bsigma_all = 0.0;  // the one sigma every range / bearing has so far, or 0
   std::vector<EventPair> timings;      // launches not yet folded into the totals below
   std::vector<EventPair> free_events;  // pairs ready for reuse
-  double timed_ms = 0.0;               // finished launches already folded (see fold_timings)
-  uint32_t timed_launches = 0;
+  double timed_ms[2] = {0.0, 0.0};     // finished launches already folded (see fold_timings), per kind
+  uint32_t timed_launches[2] = {0, 0};
   // report records of the last mcmcgpu_run_reported that used the library's own buffer
   mcmcgpu_chain_summary* reports = nullptr;  // [kMaxOwnReports][max_chains]
   uint32_t report_intervals = 0;
@@ -157,8 +159,8 @@ int fold_timings(mcmcgpu_handle h, bool wait) {
     if (kept == 0 && (wait || hipEventQuery(ev.stop) == hipSuccess)) {
       float ms = 0.f;
       HIP_TRY(h, hipEventElapsedTime(&ms, ev.start, ev.stop));
-      h->timed_ms += ms;
-      ++h->timed_launches;
+      h->timed_ms[ev.kind] += ms;
+      ++h->timed_launches[ev.kind];
       h->free_events.push_back(ev);
     } else {
       h->timings[kept++] = ev;
@@ -169,7 +171,7 @@ int fold_timings(mcmcgpu_handle h, bool wait) {
 }
 
 // An event pair for one timed launch, `start` already recorded on the stream.
-int begin_timed(mcmcgpu_handle h, EventPair* ev) {
+int begin_timed(mcmcgpu_handle h, EventPair* ev, int kind = 0) {
   if (h->timings.size() >= kMaxPendingTimings)
     if (int rc = fold_timings(h, false)) return rc;
   if (!h->free_events.empty()) {
@@ -183,6 +185,7 @@ int begin_timed(mcmcgpu_handle h, EventPair* ev) {
       return fail(h, MCMCGPU_ERR_HIP, std::string("hipEventCreate: ") + hipGetErrorString(e));
     }
   }
+  ev->kind = kind;
   hipError_t e = hipEventRecord(ev->start, h->stream);
   if (e != hipSuccess) {
     h->free_events.push_back(*ev);
@@ -690,7 +693,11 @@ int mcmcgpu_upload_problem(mcmcgpu_handle h, uint32_t T, const double* ctrl_mean
   h->a_bsd.clear();
   h->bearings_loaded = false;
   h->f_count.assign(F, 0);
-  for (uint32_t i = 0; i < N; ++i) ++h->f_count[obs_feature[i]];
+  h->f_arrivals.assign(F, {});
+  for (uint32_t i = 0; i < N; ++i) {
+    ++h->f_count[obs_feature[i]];
+    h->f_arrivals[obs_feature[i]].push_back(i);
+  }
   return lay_out(h, false);
 }
 
@@ -733,6 +740,28 @@ int mcmcgpu_append_timestep(mcmcgpu_handle h, const double* ctrl_mean, const dou
   // initial estimates continue the arrays of mcmcgpu_set_initial_estimates only without a hole
   const bool take_irel = init_state_rel && ctrl_mean && d.n_init_rel == T0;
   const bool take_ifeat = init_feat_rel && d.n_init_feat == F0;
+  // A landmark whose slots are used up moves, alone, to a region of twice the size behind everything
+  // else (the old region is left as a gap until the next full layout): every reading is moved
+  // O(1) times on average, and nothing else is touched.
+  for (uint32_t i = 0; i < n_obs && h->problem_loaded; ++i) {
+    const uint32_t f = obs_feature[i];
+    if (f >= F0 || h->f_count[f] < h->f_cap[f]) continue;
+    const uint32_t count = h->f_count[f], from = h->f_start[f], to = h->slots_used;
+    const uint64_t room = std::max<uint64_t>(32, 2 * uint64_t(h->f_cap[f]));
+    if (uint64_t(to) + room + 32 * uint64_t(F1 - F0) > d.Ncap) break;  // no room left: the full layout below compacts
+    hipLaunchKernelGGL(move_list_kernel, dim3(std::max<uint32_t>(1, std::min<uint32_t>(64, (count + 255) / 256))), dim3(256), 0,
+                       h->stream, d, f, from, to, count);
+    HIP_TRY(h, hipGetLastError());
+    h->slots_used = to + uint32_t(room);
+    h->h_ot.resize(h->slots_used, 0);
+    h->h_omu.resize(h->slots_used, 0.0);
+    std::copy_n(h->h_ot.begin() + from, count, h->h_ot.begin() + to);
+    std::copy_n(h->h_omu.begin() + from, count, h->h_omu.begin() + to);
+    for (const uint32_t arrival : h->f_arrivals[f]) h->h_tobs[arrival] = h->h_tobs[arrival] - from + to;
+    h->f_start[f] = to;
+    h->f_cap[f] = uint32_t(room);
+    h->f_start[F0] = h->slots_used;
+  }
   // does every reading find a free slot next to its landmark's list?
   bool fits = h->problem_loaded || (T0 == 0 && N0 == 0);
   std::vector<uint32_t> new_start(F1 - F0, 0);
@@ -752,7 +781,9 @@ int mcmcgpu_append_timestep(mcmcgpu_handle h, const double* ctrl_mean, const dou
     h->a_cmean.insert(h->a_cmean.end(), ctrl_mean, ctrl_mean + 3);
     h->a_cstd.insert(h->a_cstd.end(), ctrl_stddev, ctrl_stddev + 3);
   }
+  h->f_arrivals.resize(F1);
   for (uint32_t i = 0; i < n_obs; ++i) {
+    h->f_arrivals[obs_feature[i]].push_back(uint32_t(h->a_t.size()));
     h->a_t.push_back(t);
     h->a_f.push_back(obs_feature[i]);
     h->a_mean.push_back(obs_mean[i]);
@@ -1170,7 +1201,11 @@ int mcmcgpu_rebuild(mcmcgpu_handle h) {
   if (!h) return MCMCGPU_ERR_ARGUMENT;
   if (h->chains == 0) return fail(h, MCMCGPU_ERR_STATE, "no chains");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
-  return rebuild_impl(h, 0, h->chains);
+  EventPair ev;
+  if (int rc = begin_timed(h, &ev, 1)) return rc;
+  const int rc = rebuild_impl(h, 0, h->chains);
+  if (int rc2 = end_timed(h, ev, rc ? hipErrorUnknown : hipSuccess, "rebuild")) return rc ? rc : rc2;
+  return 0;
 }
 
 int mcmcgpu_scan_poses_static(int32_t device, void* stream, uint32_t chains, uint32_t n, const double* dev_rel_x,
@@ -1734,6 +1769,8 @@ int mcmcgpu_load_state(mcmcgpu_handle h, uint32_t first, uint32_t count, const d
   if (!h || !rel_poses || !feat_world) return fail(h, MCMCGPU_ERR_ARGUMENT, "null argument");
   if (!h->problem_loaded || h->chains == 0) return fail(h, MCMCGPU_ERR_STATE, "upload a problem and init chains first");
   if (count == 0 || first + count > h->chains) return fail(h, MCMCGPU_ERR_ARGUMENT, "chain range out of bounds");
+  if (h->cfg.range_bearing && !h->bearings_loaded)
+    return fail(h, MCMCGPU_ERR_STATE, "mcmcgpu_set_bearings must follow mcmcgpu_upload_problem on a range-and-bearing handle");
   Dev& d = h->d;
   const uint32_t T = d.T, F = d.F;
   if (h->next_timestep != T + 1 && !(first == 0 && count == h->chains))
@@ -1788,11 +1825,23 @@ int mcmcgpu_kernel_time(mcmcgpu_handle h, double* avg_ms, uint32_t* launches) {
   if (!h) return MCMCGPU_ERR_ARGUMENT;
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   if (int rc = fold_timings(h, true)) return rc;
-  const uint32_t n = h->timed_launches;
-  if (avg_ms) *avg_ms = n ? h->timed_ms / n : 0.0;
+  const uint32_t n = h->timed_launches[0];
+  if (avg_ms) *avg_ms = n ? h->timed_ms[0] / n : 0.0;
   if (launches) *launches = n;
-  h->timed_ms = 0.0;
-  h->timed_launches = 0;
+  h->timed_ms[0] = 0.0;
+  h->timed_launches[0] = 0;
+  return 0;
+}
+
+int mcmcgpu_rebuild_time(mcmcgpu_handle h, double* avg_ms, uint32_t* launches) {
+  if (!h) return MCMCGPU_ERR_ARGUMENT;
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  if (int rc = fold_timings(h, true)) return rc;
+  const uint32_t n = h->timed_launches[1];
+  if (avg_ms) *avg_ms = n ? h->timed_ms[1] / n : 0.0;
+  if (launches) *launches = n;
+  h->timed_ms[1] = 0.0;
+  h->timed_launches[1] = 0;
   return 0;
 }
 

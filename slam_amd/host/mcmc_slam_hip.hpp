@@ -187,6 +187,7 @@ class mcmc_slam : public slam_result_of<ControlModel, ObservationModel> {
   std::vector<double> init_rel, init_feat;  // what the initialiser says about new edges
   std::size_t next_timestep = 0;
   std::uint64_t accepts_seen = 0;
+  bool async_pending = false;  // update_async has queued updates whose accepts are not in accepts_seen
   std::uint32_t split_slices = 0, split_min_observations = 0;
 
   // `count` updates, queued: one persistent launch, or kernel sequences with sliced reading streams
@@ -240,6 +241,10 @@ class mcmc_slam : public slam_result_of<ControlModel, ObservationModel> {
   // `count` steps in one launch; returns how many were accepted.
   unsigned int update(unsigned int count) {
     if (next_timestep == 0 || count == 0) return 0;
+    if (async_pending) {  // the accept counter as it stands once the updates queued by update_async have run
+      detail::check(h, mcmcgpu_get_counters(h, nullptr, &accepts_seen, nullptr), "mcmcgpu_get_counters");
+      async_pending = false;
+    }
     run_updates(count);
     std::uint64_t acc = 0;
     detail::check(h, mcmcgpu_get_counters(h, nullptr, &acc, nullptr), "mcmcgpu_get_counters");
@@ -324,10 +329,12 @@ class mcmc_slam : public slam_result_of<ControlModel, ObservationModel> {
       result->get_feature_map()[problem.feature_ids()[f]] = feature_type::cartesian(world[2 * f], world[2 * f + 1]);
     return result;
   }
-  // updates queued without waiting for them (update(count) waits, to report the accept count)
+  // updates queued without waiting for them (update(count) waits, to report the accept count);
+  // what they accept is not reported by a later update(count): that one counts from its own start
   void update_async(unsigned int count) {
     if (next_timestep == 0 || count == 0) return;
     run_updates(count);
+    async_pending = true;
     invalidate();
   }
 

@@ -33,51 +33,58 @@ inline std::vector<position> read_positions(const std::string& path) {
   return out;
 }
 
+// Steers the simulated robot from waypoint to waypoint: a PD law on the bearing to the waypoint
+// ahead, with the steering angle and its change per step both limited.  The arithmetic is the
+// reference's (src/planar_robot/waypoint_controller.hpp:70-106, defaults waypoint_controller.cpp:20-48),
+// so that a simulated data set is the reference's bit for bit; the settings are plain members
+// where the reference reads boost::program_options.
 class waypoint_controller {
+  // The bearing to the waypoint ahead and a low-pass filtered rate of its change.
+  struct bearing_tracker {
+    double bearing = 0, rate = 0;
+    void reset() { bearing = rate = 0; }
+    void observe(double now, double dt, double time_constant) {
+      const double blend = dt / std::max(dt, time_constant);
+      rate *= 1 - blend;
+      rate += blend * (now - bearing) / dt;
+      bearing = now;
+    }
+  };
+  static double limited(double value, double bound) {
+    return std::abs(value) > bound ? (value < 0 ? -1 : 1) * bound : value;
+  }
+
+  bearing_tracker ahead;
+  double wheel = 0;         // current steering angle
+  std::size_t reached = 0;  // waypoints passed so far; the route repeats
+
+  position goal_seen_from(const pose& state) const { return -state + waypoints[reached % waypoints.size()]; }
+
  public:
-  // defaults: waypoint_controller.cpp:20-48
   std::vector<position> waypoints;
   double speed = 3.0, max_steering = 30.0 * 3.14159265358979323846 / 180,
          max_steering_rate = 20.0 * 3.14159265358979323846 / 180, proximity = 1.0, repetitions = 1.0;
   double param_P = 0.5, param_D = 2.0, smoothing = 0.5;
 
- private:
-  double steering = 0;
-  std::size_t waypoint = 0;
-  double direction = 0, direction_deriv = 0;
-
-  void next_waypoint() {
-    ++waypoint;
-    direction = 0;
-    direction_deriv = 0;
-  }
-  const position& current_waypoint() const { return waypoints[waypoint % waypoints.size()]; }
-
- public:
   pose initial_state() const {
     return waypoints.empty() ? pose() : pose::cartesian(waypoints.front().x(), waypoints.front().y(), 0.0);
   }
-  bool finished() const { return waypoint >= waypoints.size() * repetitions; }
+  bool finished() const { return reached >= waypoints.size() * repetitions; }
 
-  // PD steering towards the current waypoint, rate- and angle-limited (waypoint_controller.hpp:70-106)
+  // The control for the next dt seconds, as (speed, mean steering angle over the step).
   template <class ControlModel>
   typename ControlModel::vector_type control(const pose& state, double dt) {
-    {
-      position target;
-      while ((target = -state + current_waypoint()).distance() <= proximity) next_waypoint();
-      const double target_direction = target.direction();
-      const double alpha = dt / std::max(dt, smoothing);
-      direction_deriv *= 1 - alpha;
-      direction_deriv += alpha * (target_direction - direction) / dt;
-      direction = target_direction;
+    position goal = goal_seen_from(state);
+    while (goal.distance() <= proximity) {  // close enough: on to the next waypoint, the filter starts afresh
+      ++reached;
+      ahead.reset();
+      goal = goal_seen_from(state);
     }
-    double steering_change = param_P * direction / dt + param_D * direction_deriv;
-    if (std::abs(steering_change) > max_steering_rate * dt)
-      steering_change = (steering_change < 0 ? -1 : 1) * max_steering_rate * dt;
-    const double old_steering = steering;
-    steering += steering_change;
-    if (std::abs(steering) > max_steering) steering = (steering < 0 ? -1 : 1) * max_steering;
-    return ControlModel::from_steering(speed, (old_steering + steering) / 2);
+    ahead.observe(goal.direction(), dt, smoothing);
+    const double wanted_change = param_P * ahead.bearing / dt + param_D * ahead.rate;
+    const double before = wheel;
+    wheel = limited(before + limited(wanted_change, max_steering_rate * dt), max_steering);
+    return ControlModel::from_steering(speed, (before + wheel) / 2);
   }
 };
 

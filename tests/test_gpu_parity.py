@@ -848,6 +848,16 @@ def test_appended_timesteps_equal_one_upload():
         for name in ("kind", "index", "accepted", "log_ratio", "log_likelihood", "proposed"):
             assert np.array_equal(t1[name], t2[name]), name
     assert np.array_equal(g1.full_log_likelihood(), g2.full_log_likelihood())
+    # the lists that outgrew their slots were moved (twice each here): a second replay from scratch over the
+    # appended data walks the arrival index and the moved lists, and must give the same chains again
+    g2.init_chains(seeds)
+    g2.advance(p["T"], steps_per_timestep=3, end_steps=50)
+    g2.sync()
+    for c in range(2):
+        t1, t2 = g1.trace(c), g2.trace(c)
+        assert len(t1) == len(t2)
+        for name in ("kind", "index", "accepted", "log_ratio", "log_likelihood", "proposed"):
+            assert np.array_equal(t1[name], t2[name]), "replay after moves: " + name
     # ... and continuing an uploaded problem by appends (compact layout first, then room to grow)
     half = 100
     n = int(np.searchsorted(p["obs_t"], half, side="right"))
