@@ -50,6 +50,10 @@ struct Dev {
   const double* csd;          // [3][Tcap] control std deviations
   const uint32_t* foff;       // [Fcap+1] readings of landmark f: [foff[f], foff[f+1]), time-sorted
   const ObsRec* orec;         // [Ncap] readings, landmark-major
+  // the same readings as two arrays, what the reading streams load: 12 bytes per reading instead
+  // of the record's 16 (a stream knows its landmark from the segment it is in)
+  const double* omu;          // [Ncap] measured range
+  const uint32_t* ots;        // [Ncap] timestep
   const double* osd;          // [Ncap] std deviation of a reading
   const double* oisd;         // [Ncap] 1 / std deviation
   const uint32_t* opiv;       // [Ncap/32+1] timestep of every 32nd reading (search pivots)
@@ -389,9 +393,8 @@ struct RatioStream {
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const ObsRec rec = d.orec[r.o[u]];
-      r.t[u] = rec.t;
-      r.mu[u] = rec.mu;
+      r.t[u] = d.ots[r.o[u]];
+      r.mu[u] = d.omu[r.o[u]];
     }
   }
   MG_DEV void request_poses(uint32_t i0, const Recs& r, Poses& p) {
@@ -496,9 +499,8 @@ struct BearingStream {
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const ObsRec rec = d.orec[r.o[u]];
-      r.t[u] = rec.t;
-      r.mu[u] = rec.mu;
+      r.t[u] = d.ots[r.o[u]];
+      r.mu[u] = d.omu[r.o[u]];
       r.bm[u] = d.obear[r.o[u]];
     }
   }
@@ -1628,7 +1630,8 @@ __global__ void __launch_bounds__(256) split_eval_kernel(Dev d_by_value) {
   const double* __restrict__ w4 = d.sp_segw + 4 * size_t(c) * d.Fcap;
   const PoseXY* __restrict__ poses = d.pxy + size_t(c) * (d.Tcap + 1);
   const double* __restrict__ pth = d.pth + size_t(c) * (d.Tcap + 1);
-  const ObsRec* __restrict__ orec = d.orec;
+  const double* __restrict__ omu = d.omu;
+  const uint32_t* __restrict__ ots = d.ots;
   const double* __restrict__ obear = d.obear;
   const uint32_t total = nf ? segpre[nf] : 0;
   const uint32_t slices = active_slices(total, gridDim.x);
@@ -1675,7 +1678,10 @@ __global__ void __launch_bounds__(256) split_eval_kernel(Dev d_by_value) {
     uint32_t seg_end = pre_at(cur + 1), seg_base = lo_at(cur) - pre_at(cur);
     constexpr int U = 2;
     constexpr uint32_t stride = 256;
-    ObsRec rec[U];
+    struct {
+      double mu;
+      uint32_t t;
+    } rec[U];
     double bm[U];
     uint32_t o[U], sg[U];
     auto fetch = [&](uint32_t i0) {
@@ -1696,7 +1702,8 @@ __global__ void __launch_bounds__(256) split_eval_kernel(Dev d_by_value) {
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        rec[u] = orec[o[u]];
+        rec[u].mu = omu[o[u]];
+        rec[u].t = ots[o[u]];
         if (BEAR) bm[u] = obear[o[u]];
       }
     };
@@ -2000,6 +2007,8 @@ __global__ void append_kernel(Dev d, AppendArgs a) {
   if (i < a.n) {
     const uint32_t s = a.slot[i], f = a.f[i];
     const_cast<ObsRec*>(d.orec)[s] = ObsRec{a.mu[i], a.t, f};
+    const_cast<double*>(d.omu)[s] = a.mu[i];
+    const_cast<uint32_t*>(d.ots)[s] = a.t;
     const_cast<double*>(d.osd)[s] = a.sd[i];
     const_cast<double*>(d.oisd)[s] = 1.0 / a.sd[i];
     if (d.obear) {
@@ -2028,6 +2037,8 @@ __global__ void move_list_kernel(Dev d, uint32_t f, uint32_t from, uint32_t to, 
     const ObsRec r = d.orec[from + i];
     const uint32_t s = to + i;
     const_cast<ObsRec*>(d.orec)[s] = r;
+    const_cast<double*>(d.omu)[s] = r.mu;
+    const_cast<uint32_t*>(d.ots)[s] = r.t;
     const_cast<double*>(d.osd)[s] = d.osd[from + i];
     const_cast<double*>(d.oisd)[s] = d.oisd[from + i];
     if (d.obear) {

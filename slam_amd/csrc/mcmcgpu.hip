@@ -282,6 +282,8 @@ int lay_out(mcmcgpu_handle h, bool with_slack) {
   HIP_TRY(h, up(d.foff, h->f_start.data(), h->f_start.size() * sizeof(uint32_t)));
   HIP_TRY(h, up(d.toff, toff.data(), toff.size() * sizeof(uint32_t)));
   HIP_TRY(h, up(d.orec, orec.data(), size_t(S) * sizeof(ObsRec)));
+  HIP_TRY(h, up(d.omu, h->h_omu.data(), size_t(S) * sizeof(double)));
+  HIP_TRY(h, up(d.ots, h->h_ot.data(), size_t(S) * sizeof(uint32_t)));
   HIP_TRY(h, up(d.oisd, oisd.data(), size_t(S) * sizeof(double)));
   HIP_TRY(h, up(d.opiv, opiv.data(), opiv.size() * sizeof(uint32_t)));
   HIP_TRY(h, up(d.tobs, tobs.data(), size_t(N) * sizeof(uint32_t)));
@@ -553,6 +555,8 @@ int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out) {
   ALLOC(d.csd, 3 * size_t(d.Tcap));
   ALLOC(d.foff, size_t(d.Fcap) + 1);
   ALLOC(d.orec, d.Ncap);
+  ALLOC(d.omu, d.Ncap);
+  ALLOC(d.ots, d.Ncap);
   ALLOC(d.oisd, d.Ncap);
   ALLOC(d.opiv, size_t(d.Ncap) / 32 + 2);
   d.tblk_shift = kTimeBlockShift;
