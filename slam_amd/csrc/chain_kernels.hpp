@@ -41,6 +41,13 @@ struct alignas(16) ObsRec {
   uint32_t f;  // landmark (dense index)
 };
 
+// A reading as the streams load it: range and timestep in 12 bytes (one three-dword load).
+struct __attribute__((packed, aligned(4))) StreamRec {
+  double mu;
+  uint32_t t;
+};
+static_assert(sizeof(StreamRec) == 12, "stream records are 12 bytes");
+
 // Everything a kernel needs, passed by value.
 struct Dev {
   // ---- problem (read-only), shared by all chains -------------------------
@@ -50,10 +57,9 @@ struct Dev {
   const double* csd;          // [3][Tcap] control std deviations
   const uint32_t* foff;       // [Fcap+1] readings of landmark f: [foff[f], foff[f+1]), time-sorted
   const ObsRec* orec;         // [Ncap] readings, landmark-major
-  // the same readings as two arrays, what the reading streams load: 12 bytes per reading instead
-  // of the record's 16 (a stream knows its landmark from the segment it is in)
-  const double* omu;          // [Ncap] measured range
-  const uint32_t* ots;        // [Ncap] timestep
+  // the same readings without the landmark, what the reading streams load: 12 bytes per reading
+  // instead of the record's 16 (a stream knows its landmark from the segment it is in)
+  const StreamRec* osr;       // [Ncap]
   const double* osd;          // [Ncap] std deviation of a reading
   const double* oisd;         // [Ncap] 1 / std deviation
   const uint32_t* opiv;       // [Ncap/32+1] timestep of every 32nd reading (search pivots)
@@ -393,8 +399,9 @@ struct RatioStream {
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      r.t[u] = d.ots[r.o[u]];
-      r.mu[u] = d.omu[r.o[u]];
+      const StreamRec rec = d.osr[r.o[u]];
+      r.t[u] = rec.t;
+      r.mu[u] = rec.mu;
     }
   }
   MG_DEV void request_poses(uint32_t i0, const Recs& r, Poses& p) {
@@ -499,8 +506,9 @@ struct BearingStream {
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      r.t[u] = d.ots[r.o[u]];
-      r.mu[u] = d.omu[r.o[u]];
+      const StreamRec rec = d.osr[r.o[u]];
+      r.t[u] = rec.t;
+      r.mu[u] = rec.mu;
       r.bm[u] = d.obear[r.o[u]];
     }
   }
@@ -1630,8 +1638,7 @@ __global__ void __launch_bounds__(256) split_eval_kernel(Dev d_by_value) {
   const double* __restrict__ w4 = d.sp_segw + 4 * size_t(c) * d.Fcap;
   const PoseXY* __restrict__ poses = d.pxy + size_t(c) * (d.Tcap + 1);
   const double* __restrict__ pth = d.pth + size_t(c) * (d.Tcap + 1);
-  const double* __restrict__ omu = d.omu;
-  const uint32_t* __restrict__ ots = d.ots;
+  const StreamRec* __restrict__ osr = d.osr;
   const double* __restrict__ obear = d.obear;
   const uint32_t total = nf ? segpre[nf] : 0;
   const uint32_t slices = active_slices(total, gridDim.x);
@@ -1678,10 +1685,7 @@ __global__ void __launch_bounds__(256) split_eval_kernel(Dev d_by_value) {
     uint32_t seg_end = pre_at(cur + 1), seg_base = lo_at(cur) - pre_at(cur);
     constexpr int U = 2;
     constexpr uint32_t stride = 256;
-    struct {
-      double mu;
-      uint32_t t;
-    } rec[U];
+    StreamRec rec[U];
     double bm[U];
     uint32_t o[U], sg[U];
     auto fetch = [&](uint32_t i0) {
@@ -1702,8 +1706,7 @@ __global__ void __launch_bounds__(256) split_eval_kernel(Dev d_by_value) {
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        rec[u].mu = omu[o[u]];
-        rec[u].t = ots[o[u]];
+        rec[u] = osr[o[u]];
         if (BEAR) bm[u] = obear[o[u]];
       }
     };
@@ -2007,8 +2010,7 @@ __global__ void append_kernel(Dev d, AppendArgs a) {
   if (i < a.n) {
     const uint32_t s = a.slot[i], f = a.f[i];
     const_cast<ObsRec*>(d.orec)[s] = ObsRec{a.mu[i], a.t, f};
-    const_cast<double*>(d.omu)[s] = a.mu[i];
-    const_cast<uint32_t*>(d.ots)[s] = a.t;
+    const_cast<StreamRec*>(d.osr)[s] = StreamRec{a.mu[i], a.t};
     const_cast<double*>(d.osd)[s] = a.sd[i];
     const_cast<double*>(d.oisd)[s] = 1.0 / a.sd[i];
     if (d.obear) {
@@ -2037,8 +2039,7 @@ __global__ void move_list_kernel(Dev d, uint32_t f, uint32_t from, uint32_t to, 
     const ObsRec r = d.orec[from + i];
     const uint32_t s = to + i;
     const_cast<ObsRec*>(d.orec)[s] = r;
-    const_cast<double*>(d.omu)[s] = r.mu;
-    const_cast<uint32_t*>(d.ots)[s] = r.t;
+    const_cast<StreamRec*>(d.osr)[s] = StreamRec{r.mu, r.t};
     const_cast<double*>(d.osd)[s] = d.osd[from + i];
     const_cast<double*>(d.oisd)[s] = d.oisd[from + i];
     if (d.obear) {

@@ -282,8 +282,9 @@ int lay_out(mcmcgpu_handle h, bool with_slack) {
   HIP_TRY(h, up(d.foff, h->f_start.data(), h->f_start.size() * sizeof(uint32_t)));
   HIP_TRY(h, up(d.toff, toff.data(), toff.size() * sizeof(uint32_t)));
   HIP_TRY(h, up(d.orec, orec.data(), size_t(S) * sizeof(ObsRec)));
-  HIP_TRY(h, up(d.omu, h->h_omu.data(), size_t(S) * sizeof(double)));
-  HIP_TRY(h, up(d.ots, h->h_ot.data(), size_t(S) * sizeof(uint32_t)));
+  std::vector<StreamRec> osr(S);
+  for (uint32_t s = 0; s < S; ++s) osr[s] = StreamRec{h->h_omu[s], h->h_ot[s]};
+  HIP_TRY(h, up(d.osr, osr.data(), size_t(S) * sizeof(StreamRec)));
   HIP_TRY(h, up(d.oisd, oisd.data(), size_t(S) * sizeof(double)));
   HIP_TRY(h, up(d.opiv, opiv.data(), opiv.size() * sizeof(uint32_t)));
   HIP_TRY(h, up(d.tobs, tobs.data(), size_t(N) * sizeof(uint32_t)));
@@ -555,8 +556,7 @@ int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out) {
   ALLOC(d.csd, 3 * size_t(d.Tcap));
   ALLOC(d.foff, size_t(d.Fcap) + 1);
   ALLOC(d.orec, d.Ncap);
-  ALLOC(d.omu, d.Ncap);
-  ALLOC(d.ots, d.Ncap);
+  ALLOC(d.osr, d.Ncap);
   ALLOC(d.oisd, d.Ncap);
   ALLOC(d.opiv, size_t(d.Ncap) / 32 + 2);
   d.tblk_shift = kTimeBlockShift;
