@@ -100,12 +100,16 @@ def parse_args():
 
 
 def library_sha16():
-    """Identifies the build of the library that is running (profiles quote it)."""
+    """Identifies the library's code: a digest of its sources (slam_amd/csrc, include/mcmcgpu.h).  Profiles quote
+    it; bench.py quotes a profile's counter figures only when they were taken on the same code."""
+    import glob
     import hashlib
 
-    from slam_amd import capi
-    with open(capi._LIB_PATH, "rb") as f:
-        return hashlib.sha256(f.read()).hexdigest()[:16]
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "slam_amd", "csrc", "*")) + [os.path.join(ROOT, "include", "mcmcgpu.h")]):
+        with open(path, "rb") as f:
+            h.update(os.path.basename(path).encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(problem, seed, target_seconds, all_seeds=None):
