@@ -1275,9 +1275,13 @@ MG_PIECE void piece_driver_advance(DevArgs dp, SharedLds sp, uint32_t c) {
   driver_advance(*(const Dev*)dp, c, *(Shared*)sp);
 }
 
+// The evaluation is compiled INTO the kernel (one kernel per observation model), the serial pieces
+// around it are calls: a called evaluation saves and restores the callee-saved half of its 128
+// registers in every lane at every proposal -- about 100 KB each way per proposal, an eighth of
+// the kernel's memory traffic -- while the serial pieces, called by one lane, save next to nothing.
 template <bool RB>
-MG_PIECE double piece_eval(DevArgs dp, SharedLds sp, uint32_t c, int op, uint32_t idx, double qx, double qy,
-                           double qth, uint32_t nf) {
+MG_DEV double inline_eval(DevArgs dp, SharedLds sp, uint32_t c, int op, uint32_t idx, double qx, double qy,
+                          double qth, uint32_t nf) {
   const Dev& d = *(const Dev*)dp;
   Shared& S = *(Shared*)sp;
   unsigned long long units = 0;
@@ -1334,6 +1338,7 @@ MG_PIECE void piece_commit(DevArgs dp, SharedLds sp, uint32_t c, uint32_t idx, d
 struct TreeTops {
   uint32_t sw_n, sw_shift, fw_n, fw_shift;
 };
+template <bool RB>
 __global__ void advance_kernel(Dev d, uint32_t first_tn, uint32_t Tcur0, uint32_t upto, uint32_t steps_per_ts,
                                uint32_t end_steps, uint32_t grow, TreeTops tops) {
   __shared__ Shared S;
@@ -1341,7 +1346,6 @@ __global__ void advance_kernel(Dev d, uint32_t first_tn, uint32_t Tcur0, uint32_
   const DevArgs dp = (DevArgs)__builtin_amdgcn_kernarg_segment_ptr();
   const SharedLds sp = (SharedLds)&S;
   const uint32_t c = blockIdx.x;
-  const bool bearings = d.obear != nullptr;
   chain_state_load(d, c, S);
   {  // nodes beyond a tree's current size hold nothing yet; they are written (through) before they are read
     const double* sw = d.sw + size_t(c) * d.Tcap;
@@ -1376,8 +1380,7 @@ __global__ void advance_kernel(Dev d, uint32_t first_tn, uint32_t Tcur0, uint32_
     const uint32_t idx = S.idx;
     const double qx = S.q[0], qy = S.q[1], qth = S.q[2];
     const uint32_t Tcur = S.Tcur, nf = S.nf;
-    const double r = bearings ? piece_eval<true>(dp, sp, c, op, idx, qx, qy, qth, nf)
-                              : piece_eval<false>(dp, sp, c, op, idx, qx, qy, qth, nf);
+    const double r = inline_eval<RB>(dp, sp, c, op, idx, qx, qy, qth, nf);
     MG_STAMP(te1);
     if (op != OP_EVAL_STATE) MG_PHASE_ADD(S, 3, td1, te1);
     if (threadIdx.x == 0) piece_finish_update(dp, sp, c, idx, r);

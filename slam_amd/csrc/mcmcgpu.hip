@@ -975,14 +975,15 @@ int mcmcgpu_advance(mcmcgpu_handle h, uint32_t upto, uint32_t steps_per_timestep
   const uint32_t tree_size = std::max(upto, edges_grown(h)) + 1;
   const TreeTops tops = plan_tree_tops(h, tree_size);
   const size_t dyn_lds = (size_t(tops.sw_n) + tops.fw_n) * sizeof(double);
+  auto* const kernel = h->cfg.range_bearing ? advance_kernel<true> : advance_kernel<false>;  // one per observation model
   if (dyn_lds > h->advance_lds_allowed) {
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(advance_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    int(kLdsPerCu - kAdvanceStaticLds)));
     h->advance_lds_allowed = kLdsPerCu - kAdvanceStaticLds;
   }
   EventPair ev;
   if (int rc = begin_timed(h, &ev)) return rc;
-  hipLaunchKernelGGL(advance_kernel, dim3(h->chains), dim3(h->nthreads), dyn_lds, h->stream, h->d, h->next_timestep,
+  hipLaunchKernelGGL(kernel, dim3(h->chains), dim3(h->nthreads), dyn_lds, h->stream, h->d, h->next_timestep,
                      edges_grown(h), upto, steps_per_timestep, end_steps, grow ? 1u : 0u, tops);
   if (int rc = end_timed(h, ev, hipGetLastError(), "advance_kernel")) return rc;
   if (grow) h->next_timestep = upto + 1;

@@ -73,8 +73,8 @@ def main():
                 # this gather pattern with tools/stream_probe: FETCH_SIZE tallies it at about half) + writes
                 import datetime
                 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-                import bench
-                sha = bench.library_sha16()
+                import bench as bench_module
+                sha = bench_module.library_sha16()
                 rec = {"workload": bench["config"]["workload"], "updates_per_step": bench["config"]["updates_per_step"],
                        "library_sha16": sha, "date": datetime.date.today().isoformat(), "commit": os.environ.get("GRAFT_COMMIT"),
                        "fetch_size_reported_bytes": fv * 1024, "write_size_bytes": wv * 1024,
