@@ -48,6 +48,17 @@ struct __attribute__((packed, aligned(4))) StreamRec {
 };
 static_assert(sizeof(StreamRec) == 12, "stream records are 12 bytes");
 
+// Where the readings of one landmark stand relative to one block of 2^tblk_shift timesteps: how many
+// were taken before the block, how many inside it, and -- when those inside were taken at consecutive
+// timesteps (one visit of the robot) -- the first of these timesteps, which turns "how many readings
+// up to timestep t" into arithmetic.  One 16-byte load.
+struct alignas(16) TimeBlock {
+  uint32_t before, count;
+  uint32_t run_from;  // timestep of the block's first reading when they are consecutive, else kNoRun
+  uint32_t pad;
+};
+constexpr uint32_t kNoRun = 0xFFFFFFFFu;
+
 // Everything a kernel needs, passed by value.
 struct Dev {
   // ---- problem (read-only), shared by all chains -------------------------
@@ -63,10 +74,12 @@ struct Dev {
   const double* osd;          // [Ncap] std deviation of a reading
   const double* oisd;         // [Ncap] 1 / std deviation
   const uint32_t* opiv;       // [Ncap/32+1] timestep of every 32nd reading (search pivots)
-  // [Fcap][tblk_stride] readings of landmark f taken before timestep b << tblk_shift, for the
-  // boundaries b = 0 .. tblk_n that the last layout of the problem covered
-  const uint32_t* tblk;
-  uint32_t tblk_shift, tblk_n, tblk_stride;
+  // [tblk_rows][Fcap] landmark f against the block of timesteps [b << tblk_shift, (b + 1) << tblk_shift),
+  // for the blocks b = 0 .. tblk_n - 1 that the last layout of the problem covered; row tblk_n holds
+  // the readings before the end of the last block.  Block-major: one proposal asks for the same
+  // block of every landmark, so neighbouring lanes load neighbouring entries.
+  const TimeBlock* tblk;
+  uint32_t tblk_shift, tblk_n, tblk_rows;
   const uint32_t* toff;       // [Tcap+2] arrivals at timestep t: tobs[toff[t] .. toff[t+1])
   const uint32_t* tobs;       // [Ncap] arrival order -> landmark-major position
   const uint32_t* ffirst;     // [Fcap] timestep of a landmark's first reading
@@ -91,6 +104,10 @@ struct Dev {
   uint32_t* fpar;               // [C][Fcap]   parent reading, as position inside the landmark's list
   uint32_t* fcnt;               // [C][Fcap]   readings of the landmark seen so far
   uint32_t* fpt;                // [C][Fcap]   parent timestep
+  // [C][Fcap] the parent's world pose: a copy of pose-table entry fpt, rewritten by the same
+  // arithmetic whenever that entry is, so a proposal reads its landmarks' parents with neighbouring
+  // lanes on neighbouring addresses instead of one scattered table line per landmark
+  double *fpx, *fpy, *fpth;
   uint32_t* flast;              // [C][Fcap]   timestep of the latest reading seen
   uint32_t* nf;                 // [C]         landmarks known
   double* ll;                   // [C]         chain log likelihood
@@ -247,6 +264,16 @@ MG_DEV Pose world_pose(const Dev& d, uint32_t c, uint32_t k) {
   const size_t i = size_t(c) * (d.Tcap + 1) + k;
   const PoseXY p = d.pxy[i];
   return Pose{p.x, p.y, d.pth[i]};
+}
+
+// The parent pose of landmark entry fi = c * Fcap + f, from its copy beside the landmark.
+MG_DEV Pose parent_pose(const Dev& d, size_t fi) { return Pose{d.fpx[fi], d.fpy[fi], d.fpth[fi]}; }
+// Takes the copy anew from the pose table (the landmark got a parent, or the table was rebuilt).
+MG_DEV void keep_parent_pose(const Dev& d, uint32_t c, size_t fi, uint32_t pt) {
+  const Pose p = world_pose(d, c, pt);
+  d.fpx[fi] = p.x;
+  d.fpy[fi] = p.y;
+  d.fpth[fi] = p.th;
 }
 
 // Appends pose Tcur+1 = P[Tcur] o rel (lane 0, graph growth).
@@ -704,7 +731,7 @@ MG_DEV double eval_feature_edge(const Dev& d, uint32_t c, Shared& S, uint32_t f,
                                 unsigned long long& units) {
   const size_t fi = size_t(c) * d.Fcap + f;
   if (threadIdx.x == 0) {
-    const Pose Pp = world_pose(d, c, d.fpt[fi]);
+    const Pose Pp = parent_pose(d, fi);
     const Vec2 wo = act(Pp, Vec2{d.fex[fi], d.fey[fi]});
     const Vec2 wn = act(Pp, e_new);
     S.seglo[0] = d.foff[f];
@@ -722,22 +749,29 @@ MG_DEV double eval_feature_edge(const Dev& d, uint32_t c, Shared& S, uint32_t f,
 }
 
 // upper_bound of timestep t in the time-sorted readings [lo, hi) of landmark f.  Two tables cut the
-// search short: per landmark, how many of its readings precede each boundary of a block of
-// 2^tblk_shift timesteps (one load of two neighbouring entries leaves the readings of one block,
-// a visit's worth, to search); and, for timesteps the table does not cover yet (data appended
-// since the last layout), the timestep of every 32nd reading, which narrows the range to at most 32
-// readings, so the search touches a few cache lines instead of log2(hi - lo) scattered ones.
+// search short.  Per landmark and block of 2^tblk_shift timesteps, a TimeBlock: when the block's
+// readings are one run of consecutive timesteps (the usual case: one visit) the answer is
+// arithmetic on that one entry, else the entry leaves the readings of one block to search.  And,
+// for timesteps the table does not cover yet (data appended since the last layout), the timestep of
+// every 32nd reading, which narrows the range to at most 32 readings, so the search touches a few
+// cache lines instead of log2(hi - lo) scattered ones.
 MG_DEV uint32_t split_readings(const Dev& d, uint32_t f, uint32_t lo, uint32_t hi, uint32_t t) {
   uint32_t a = lo, b = hi;
   if (d.tblk_n) {
-    const uint32_t* row = d.tblk + size_t(f) * d.tblk_stride;
     const uint32_t q = t >> d.tblk_shift;
+    const TimeBlock tb = d.tblk[size_t(q < d.tblk_n ? q : d.tblk_n) * d.Fcap + f];
+    const uint32_t ra = lo + tb.before;
     if (q < d.tblk_n) {
-      const uint32_t ra = lo + row[q], rb = lo + row[q + 1];
+      if (tb.run_from != kNoRun) {  // readings ra, ra + 1, ... were taken at run_from, run_from + 1, ...
+        uint32_t upto = t >= tb.run_from ? t - tb.run_from + 1 : 0;
+        if (upto > tb.count) upto = tb.count;
+        const uint32_t r = ra + upto;
+        return r < hi ? r : hi;
+      }
+      const uint32_t rb = ra + tb.count;
       a = ra < hi ? ra : hi;
       b = rb < hi ? rb : hi;
     } else {
-      const uint32_t ra = lo + row[d.tblk_n];
       a = ra < hi ? ra : hi;
     }
   }
@@ -808,7 +842,7 @@ MG_DEV double eval_state_edge(const Dev& d, uint32_t c, Shared& S, uint32_t t, c
         const uint32_t lo = d.foff[f], hi = lo + d.fcnt[fbase + f];
         const uint32_t pt = d.fpt[fbase + f];
         const Vec2 e{d.fex[fbase + f], d.fey[fbase + f]};
-        const Pose Pp = world_pose(d, c, pt);
+        const Pose Pp = parent_pose(d, fbase + f);
         const uint32_t a = split_readings(d, f, lo, hi, t);
         const Vec2 w = act(Pp, e);
         Vec2 wn;
@@ -869,17 +903,33 @@ MG_DEV PoseMove pose_move_of(const Dev& d, uint32_t c, uint32_t t, const Pose& q
   m.to_y = A.y;
   return m;
 }
-MG_DEV void move_pose(const Dev& d, size_t i, const PoseMove& m) {
-  const PoseXY p = d.pxy[i];
+MG_DEV PoseXY moved(const PoseMove& m, const PoseXY& p) {
   const double dx = p.x - m.pivot_x, dy = p.y - m.pivot_y;
-  d.pxy[i] = PoseXY{m.to_x + (m.c * dx - m.s * dy), m.to_y + (m.s * dx + m.c * dy)};
+  return PoseXY{m.to_x + (m.c * dx - m.s * dy), m.to_y + (m.s * dx + m.c * dy)};
+}
+MG_DEV void move_pose(const Dev& d, size_t i, const PoseMove& m) {
+  d.pxy[i] = moved(m, d.pxy[i]);
   d.pth[i] += m.dth;
 }
-MG_DEV void commit_state_edge(const Dev& d, uint32_t c, uint32_t t, const Pose& q, uint32_t Tcur) {
+// The copies of parent poses after edge t move exactly as their table entries do (all lanes).
+MG_DEV void move_parent_poses(const Dev& d, uint32_t c, uint32_t t, uint32_t nf, const PoseMove& m) {
+  const size_t fbase = size_t(c) * d.Fcap;
+  for (uint32_t f = threadIdx.x; f < nf; f += blockDim.x) {
+    const size_t fi = fbase + f;
+    if (d.fpt[fi] > t) {
+      const PoseXY p = moved(m, PoseXY{d.fpx[fi], d.fpy[fi]});
+      d.fpx[fi] = p.x;
+      d.fpy[fi] = p.y;
+      d.fpth[fi] += m.dth;
+    }
+  }
+}
+MG_DEV void commit_state_edge(const Dev& d, uint32_t c, uint32_t t, const Pose& q, uint32_t Tcur, uint32_t nf) {
   const size_t base = size_t(c) * (d.Tcap + 1);
   const PoseMove m = pose_move_of(d, c, t, q);
   __syncthreads();  // every lane holds the old pivot before anything is overwritten
   for (uint32_t k = t + 1 + threadIdx.x; k <= Tcur; k += blockDim.x) move_pose(d, base + k, m);
+  move_parent_poses(d, c, t, nf, m);
 }
 
 // ---------------------------------------------------------------------------
@@ -1100,6 +1150,7 @@ MG_DEV bool driver_arrival(const Dev& d, uint32_t c, Shared& S, uint32_t o) {
     d.fpar[fi] = 0;
     d.fcnt[fi] = 1;
     d.fpt[fi] = t;
+    keep_parent_pose(d, c, fi, t);
     d.flast[fi] = t;
     wt::push_back(landmark_tree(d, c, S), f, edge_weight_from_log_pdf(reading_proposal_log_pdf(m, est), 2.0, nullptr));
     S.w_dirty = 1;
@@ -1110,14 +1161,14 @@ MG_DEV bool driver_arrival(const Dev& d, uint32_t c, Shared& S, uint32_t o) {
   const uint32_t rel = o - d.foff[f];
   d.fcnt[fi] = rel + 1;
   d.flast[fi] = t;
-  const uint32_t pt = d.fpt[fi];
-  const Vec2 w = act(world_pose(d, c, pt), Vec2{d.fex[fi], d.fey[fi]});
+  const Vec2 w = act(parent_pose(d, fi), Vec2{d.fex[fi], d.fey[fi]});
   const Vec2 est = act_inverse(world_pose(d, c, t), w);
   S.ll += reading_log_pdf(m, est);
   const double par_mu = d.orec[d.foff[f] + d.fpar[fi]].mu;
   if (fabs(mu) < fabs(par_mu)) {  // more_accurate_than, range_bearing_model.hpp:141-143
     d.fpar[fi] = rel;
     d.fpt[fi] = t;
+    keep_parent_pose(d, c, fi, t);
     d.fex[fi] = est.x;
     d.fey[fi] = est.y;
     // update(feature_edge, false), :320
@@ -1320,7 +1371,7 @@ MG_PIECE void piece_commit(DevArgs dp, SharedLds sp, uint32_t c, uint32_t idx, d
                            uint32_t Tcur) {
   const Dev& d = *(const Dev*)dp;
   Shared& S = *(Shared*)sp;
-  commit_state_edge(d, c, idx, Pose{qx, qy, qth}, Tcur);
+  commit_state_edge(d, c, idx, Pose{qx, qy, qth}, Tcur, S.nf);
   if (threadIdx.x == 0) {
     const size_t ri = size_t(c) * d.Tcap + idx;
     d.relx[ri] = qx;
@@ -1481,8 +1532,9 @@ __global__ void split_ends_kernel(Dev d_by_value, uint32_t Tcur, uint32_t slices
   if (S.op == OP_EVAL_STATE && S.accept) {
     const Pose q{S.q[0], S.q[1], S.q[2]};
     if (defer_commit) {  // split_commit_kernel moves the poses, with many workgroups
+      const PoseMove m = pose_move_of(d, c, S.idx, q);
+      move_parent_poses(d, c, S.idx, S.nf, m);  // few enough for this workgroup
       if (threadIdx.x == 0) {
-        const PoseMove m = pose_move_of(d, c, S.idx, q);
         ChainCtl& k = d.ctl[c];
         k.move_from = S.idx + 1;
         k.move_pivot[0] = m.pivot_x;
@@ -1494,7 +1546,7 @@ __global__ void split_ends_kernel(Dev d_by_value, uint32_t Tcur, uint32_t slices
         k.move_dth = m.dth;
       }
     } else {
-      commit_state_edge(d, c, S.idx, q, Tcur);
+      commit_state_edge(d, c, S.idx, q, Tcur, S.nf);
     }
     __syncthreads();  // the old relative angle has been read
     if (threadIdx.x == 0) {
@@ -1544,7 +1596,7 @@ MG_DEV uint32_t split_setup_landmark(const Dev& d, uint32_t c, uint32_t f, const
       const Pose Pt = world_pose(d, c, t), Pt1 = world_pose(d, c, t + 1);
       const uint32_t lo = d.foff[f], hi = lo + d.fcnt[fi], pt = d.fpt[fi];
       const uint32_t a = split_readings(d, f, lo, hi, t);
-      w = act(world_pose(d, c, pt), Vec2{d.fex[fi], d.fey[fi]});
+      w = act(parent_pose(d, fi), Vec2{d.fex[fi], d.fey[fi]});
       if (t < pt) {
         wn = act(Pt, act(q, act_inverse(Pt1, w)));
         slo = lo;
@@ -1556,7 +1608,7 @@ MG_DEV uint32_t split_setup_landmark(const Dev& d, uint32_t c, uint32_t f, const
       }
     }
   } else if (k.op == OP_EVAL_FEATURE && f == k.idx) {
-    const Pose Pp = world_pose(d, c, d.fpt[fi]);
+    const Pose Pp = parent_pose(d, fi);
     w = act(Pp, Vec2{d.fex[fi], d.fey[fi]});
     wn = act(Pp, Vec2{k.q[0], k.q[1]});
     len = d.fcnt[fi];
@@ -1801,7 +1853,7 @@ __global__ void commit_kernel(Dev d, uint32_t c, int kind, uint32_t idx, double 
       const size_t ri = size_t(c) * d.Tcap + idx;
       control_part = control_log_pdf(mu, sd, q) - control_log_pdf(mu, sd, Pose{d.relx[ri], d.rely[ri], d.relth[ri]});
     }
-    commit_state_edge(d, c, idx, q, Tcur);
+    commit_state_edge(d, c, idx, q, Tcur, d.nf[c]);
     if (threadIdx.x == 0) {
       const size_t ri = size_t(c) * d.Tcap + idx;
       d.relx[ri] = q.x;
@@ -2264,6 +2316,15 @@ __global__ void features_from_world_kernel(Dev d, uint32_t first, uint32_t F, co
   const Vec2 e = act_inverse(world_pose(d, c, d.fpt[fi]), Vec2{world[2 * size_t(f)], world[2 * size_t(f) + 1]});
   d.fex[fi] = e.x;
   d.fey[fi] = e.y;
+}
+
+// The copies of the landmarks' parent poses, taken anew from pose tables that a scan has just
+// rewritten; grid = (ceil(Fcap / block), chains), chains first .. first + gridDim.y - 1.
+__global__ void parent_poses_kernel(Dev d, uint32_t first) {
+  const uint32_t c = first + blockIdx.y, f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= d.nf[c]) return;
+  const size_t fi = size_t(c) * d.Fcap + f;
+  keep_parent_pose(d, c, fi, d.fpt[fi]);
 }
 
 // Scan self-test over the integer affine group (exact): the chained scan that builds the pose

@@ -265,20 +265,29 @@ int lay_out(mcmcgpu_handle h, bool with_slack) {
   }
   for (uint32_t t = 0; t <= T; ++t) toff[t + 1] += toff[t];
   for (size_t i = 0; 32 * i < S; ++i) opiv[i] = h->h_ot[32 * i];
-  // per landmark: readings before each block boundary b << shift, b = 0 .. nb, where the last boundary
-  // is not beyond T + 1 (readings appended later are all at or past it, so the counts stay true)
+  // per block of 2^shift timesteps and landmark: readings before the block, inside it, and whether
+  // those inside are one run of consecutive timesteps.  The last block ends at or before T + 1
+  // (readings appended later are all past it, so the counts stay true); row nb = before its end.
   const uint32_t nb = (T + 1) >> d.tblk_shift;
-  std::vector<uint32_t> tblk(size_t(F) * d.tblk_stride, 0);
+  std::vector<TimeBlock> tblk(size_t(nb + 1) * d.Fcap, TimeBlock{0, 0, 0, 0});
   for (uint32_t f = 0; f < F; ++f) {
-    uint32_t* row = tblk.data() + size_t(f) * d.tblk_stride;
     uint32_t seen = 0;
     const uint32_t first = h->f_start[f], count = h->f_count[f];
-    for (uint32_t bnd = 0; bnd <= nb; ++bnd) {
-      while (seen < count && h->h_ot[first + seen] < (bnd << d.tblk_shift)) ++seen;
-      row[bnd] = seen;
+    for (uint32_t blk = 0; blk <= nb; ++blk) {
+      TimeBlock& tb = tblk[size_t(blk) * d.Fcap + f];
+      tb.before = seen;
+      if (blk == nb) break;
+      const uint32_t end = (blk + 1) << d.tblk_shift;
+      bool run = true;
+      while (seen < count && h->h_ot[first + seen] < end) {
+        run = run && h->h_ot[first + seen] == h->h_ot[first + tb.before] + (seen - tb.before);
+        ++seen;
+      }
+      tb.count = seen - tb.before;
+      tb.run_from = !run ? kNoRun : (tb.count ? h->h_ot[first + tb.before] : 0);
     }
   }
-  HIP_TRY(h, up(d.tblk, tblk.data(), tblk.size() * sizeof(uint32_t)));
+  HIP_TRY(h, up(d.tblk, tblk.data(), tblk.size() * sizeof(TimeBlock)));
   HIP_TRY(h, up(d.foff, h->f_start.data(), h->f_start.size() * sizeof(uint32_t)));
   HIP_TRY(h, up(d.toff, toff.data(), toff.size() * sizeof(uint32_t)));
   HIP_TRY(h, up(d.orec, orec.data(), size_t(S) * sizeof(ObsRec)));
@@ -433,6 +442,9 @@ int rebuild_impl(mcmcgpu_handle h, uint32_t first, uint32_t count) {
   a.seg_len = plan.seg_len;
   a.tot = h->scan_tot;
   HIP_TRY(h, launch_scan(h->stream, a, count));
+  // the landmarks' copies of their parent poses follow the rewritten tables
+  parent_poses_kernel<<<dim3((d.Fcap + 255) / 256, count), 256, 0, h->stream>>>(d, first);
+  HIP_TRY(h, hipGetLastError());
   return 0;
 }
 
@@ -560,9 +572,9 @@ int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out) {
   ALLOC(d.oisd, d.Ncap);
   ALLOC(d.opiv, size_t(d.Ncap) / 32 + 2);
   d.tblk_shift = kTimeBlockShift;
-  d.tblk_stride = (d.Tcap >> kTimeBlockShift) + 3;
+  d.tblk_rows = (d.Tcap >> kTimeBlockShift) + 3;
   d.tblk_n = 0;
-  ALLOC(d.tblk, size_t(d.Fcap) * d.tblk_stride);
+  ALLOC(d.tblk, size_t(d.Fcap) * d.tblk_rows);
   ALLOC(d.osd, d.Ncap);
   if (cfg->range_bearing) {
     ALLOC(d.obear, d.Ncap);
@@ -587,6 +599,9 @@ int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out) {
   ALLOC(d.fpar, C * d.Fcap);
   ALLOC(d.fcnt, C * d.Fcap);
   ALLOC(d.fpt, C * d.Fcap);
+  ALLOC(d.fpx, C * d.Fcap);
+  ALLOC(d.fpy, C * d.Fcap);
+  ALLOC(d.fpth, C * d.Fcap);
   ALLOC(d.flast, C * d.Fcap);
   ALLOC(d.nf, C);
   ALLOC(d.ll, C);
