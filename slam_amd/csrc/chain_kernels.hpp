@@ -66,6 +66,7 @@ struct Dev {
   uint32_t Tcap, Fcap, Ncap;  // capacities (array strides)
   const double* cmu;          // [3][Tcap] control means
   const double* csd;          // [3][Tcap] control std deviations
+  const double* cld;          // [Tcap] log csd[0] + log csd[1] + log csd[2]: the log-density's constant
   const uint32_t* foff;       // [Fcap+1] readings of landmark f: [foff[f], foff[f+1]), time-sorted
   const ObsRec* orec;         // [Ncap] readings, landmark-major
   // the same readings without the landmark, what the reading streams load: 12 bytes per reading
@@ -97,6 +98,7 @@ struct Dev {
   // ---- chains --------------------------------------------------------------
   uint32_t C;
   double *relx, *rely, *relth;  // [C][Tcap]   relative pose of state edge t
+  double* clp;                  // [C][Tcap]   the control model's log density of that relative pose
   PoseXY* pxy;                  // [C][Tcap+1] world translation of pose k
   double* pth;                  // [C][Tcap+1] its (unwrapped) angle
   double *sw, *fw;              // [C][Tcap], [C][Fcap] weight trees
@@ -950,12 +952,13 @@ MG_DEV Reading load_reading(const Dev& d, uint32_t o) {
 // bearing (:84-86): inv_observe of two normals drawn in index order (random.hpp:94-100).
 MG_DEV Vec2 propose_landmark(const Dev& d, Shared& S, const Reading& m);
 
-MG_DEV void load_control(const Dev& d, uint32_t t, double mu[3], double sd[3]) {
+MG_DEV void load_control(const Dev& d, uint32_t t, double mu[3], double sd[3], double& log_det) {
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     mu[i] = d.cmu[size_t(i) * d.Tcap + t];
     sd[i] = d.csd[size_t(i) * d.Tcap + t];
   }
+  log_det = d.cld[t];
 }
 
 MG_DEV void write_trace(const Dev& d, uint32_t c, Shared& S, int kind, uint32_t idx, const double q[3], double llr,
@@ -997,8 +1000,8 @@ MG_DEV Vec2 propose_landmark(const Dev& d, Shared& S, const Reading& m) {
 // mcmc_slam::add_state_edge (mcmc_slam.hpp:227-246) for edge Tcur
 MG_DEV void driver_add_state_edge(const Dev& d, uint32_t c, Shared& S) {
   const uint32_t t = S.Tcur;
-  double mu[3], sd[3];
-  load_control(d, t, mu, sd);
+  double mu[3], sd[3], ld;
+  load_control(d, t, mu, sd, ld);
   // with an initialiser its estimate is taken, else the proposal's initial value (:233-237)
   const Pose est = t < d.n_init_rel ? Pose{d.init_rel[3 * size_t(t)], d.init_rel[3 * size_t(t) + 1], d.init_rel[3 * size_t(t) + 2]}
                                     : control_inv_observe(mu);
@@ -1007,7 +1010,8 @@ MG_DEV void driver_add_state_edge(const Dev& d, uint32_t c, Shared& S) {
   d.rely[ri] = est.y;
   d.relth[ri] = est.th;
   append_pose(d, c, t, est);
-  const double lp = control_log_pdf(mu, sd, est);
+  const double lp = control_log_pdf(mu, sd, ld, est);
+  d.clp[ri] = lp;
   wt::push_back(state_tree(d, c, S), t, edge_weight_from_log_pdf(lp, 3.0, nullptr));
   S.w_dirty = 1;
   S.ll += lp;
@@ -1042,15 +1046,15 @@ MG_DEV bool driver_begin_update(const Dev& d, uint32_t c, Shared& S) {
       S.failed = 1;
       return false;
     }
-    double mu[3], sd[3], v[3];
-    load_control(d, t, mu, sd);
+    double mu[3], sd[3], v[3], ld;
+    load_control(d, t, mu, sd, ld);
+    // the current relative pose's log density is kept from when that pose was set
+    const double old_pll = d.clp[size_t(c) * d.Tcap + t];
     for (int i = 0; i < 3; ++i) v[i] = rng_normal(S.rng);
     for (int i = 0; i < 3; ++i) v[i] = v[i] * sd[i] + mu[i];
     const Pose q = control_inv_observe(v);
-    const size_t ri = size_t(c) * d.Tcap + t;
-    const Pose cur{d.relx[ri], d.rely[ri], d.relth[ri]};
-    S.new_pll = control_log_pdf(mu, sd, q);
-    S.old_pll = control_log_pdf(mu, sd, cur);
+    S.new_pll = control_log_pdf(mu, sd, ld, q);
+    S.old_pll = old_pll;
     S.op = OP_EVAL_STATE;
     S.idx = t;
     S.q[0] = q.x;
@@ -1110,6 +1114,7 @@ MG_DEV bool driver_finish_update(const Dev& d, uint32_t c, Shared& S, double obs
   if (accept) {
     if (is_state) {
       S.llc += S.new_pll - S.old_pll;
+      d.clp[size_t(c) * d.Tcap + S.idx] = S.new_pll;
       wt::set(sw, S.Tcur, S.idx, new_weight);
       // the relative pose itself is stored after commit_state_edge has moved
       // the pose table (that needs the old angle)
@@ -1828,11 +1833,11 @@ __global__ void eval_kernel(Dev d_by_value, uint32_t c, int kind, uint32_t idx, 
     r = d.obear ? eval_state_edge<true>(d, c, S, idx, q, d.nf[c], units)
                 : eval_state_edge<false>(d, c, S, idx, q, d.nf[c], units);
     if (threadIdx.x == 0) {
-      double mu[3], sd[3];
-      load_control(d, idx, mu, sd);
+      double mu[3], sd[3], ld;
+      load_control(d, idx, mu, sd, ld);
       const size_t ri = size_t(c) * d.Tcap + idx;
       const Pose cur{d.relx[ri], d.rely[ri], d.relth[ri]};
-      r = (control_log_pdf(mu, sd, q) - control_log_pdf(mu, sd, cur)) + r;
+      r = (control_log_pdf(mu, sd, ld, q) - control_log_pdf(mu, sd, ld, cur)) + r;
     }
   } else {
     r = d.obear ? eval_feature_edge<true>(d, c, S, idx, Vec2{q0, q1}, units)
@@ -1848,10 +1853,12 @@ __global__ void commit_kernel(Dev d, uint32_t c, int kind, uint32_t idx, double 
     const Pose q{q0, q1, q2};
     double control_part = 0.0;  // what the edge's own control term changes by (kept apart for tempering)
     if (threadIdx.x == 0) {
-      double mu[3], sd[3];
-      load_control(d, idx, mu, sd);
+      double mu[3], sd[3], ld;
+      load_control(d, idx, mu, sd, ld);
       const size_t ri = size_t(c) * d.Tcap + idx;
-      control_part = control_log_pdf(mu, sd, q) - control_log_pdf(mu, sd, Pose{d.relx[ri], d.rely[ri], d.relth[ri]});
+      const double new_part = control_log_pdf(mu, sd, ld, q);
+      control_part = new_part - control_log_pdf(mu, sd, ld, Pose{d.relx[ri], d.rely[ri], d.relth[ri]});
+      d.clp[ri] = new_part;
     }
     commit_state_edge(d, c, idx, q, Tcur, d.nf[c]);
     if (threadIdx.x == 0) {
@@ -1993,10 +2000,10 @@ __global__ void full_ll_kernel(Dev d, uint32_t first, uint32_t Tcur, double* out
   const uint32_t segcap = nthr < uint32_t(kMaxSeg) ? nthr : uint32_t(kMaxSeg);
   double acc = 0.0;
   for (uint32_t t = tid; t < Tcur; t += nthr) {
-    double mu[3], sd[3];
-    load_control(d, t, mu, sd);
+    double mu[3], sd[3], ld;
+    load_control(d, t, mu, sd, ld);
     const size_t ri = size_t(c) * d.Tcap + t;
-    acc += control_log_pdf(mu, sd, Pose{d.relx[ri], d.rely[ri], d.relth[ri]});
+    acc += control_log_pdf(mu, sd, ld, Pose{d.relx[ri], d.rely[ri], d.relth[ri]});
   }
   if (out_controls) {
     const double controls = block_sum(acc, S);
@@ -2050,6 +2057,13 @@ struct AppendArgs {
   double mu[kAppendMax], sd[kAppendMax], bmu[kAppendMax], bsd[kAppendMax];
   double ifeat[kAppendMax][2];
 };
+// The constant of every control's log density, from the uploaded deviations; one lane per control.
+__global__ void control_log_det_kernel(Dev d, uint32_t n) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const_cast<double*>(d.cld)[t] = control_log_det(d.csd[t], d.csd[size_t(d.Tcap) + t], d.csd[2 * size_t(d.Tcap) + t]);
+}
+
 __global__ void append_kernel(Dev d, AppendArgs a) {
   const uint32_t i = threadIdx.x;
   if (i == 0) {
@@ -2059,6 +2073,7 @@ __global__ void append_kernel(Dev d, AppendArgs a) {
         const_cast<double*>(d.csd)[size_t(k) * d.Tcap + (a.t - 1)] = a.cs[k];
         if (a.has_init_rel) const_cast<double*>(d.init_rel)[3 * size_t(a.t - 1) + k] = a.irel[k];
       }
+      const_cast<double*>(d.cld)[a.t - 1] = control_log_det(a.cs[0], a.cs[1], a.cs[2]);
     }
     const_cast<uint32_t*>(d.toff)[a.t + 1] = a.arrivals_end;
   }
@@ -2269,10 +2284,11 @@ __global__ void reweigh_kernel(Dev d, uint32_t first, uint32_t Tcur) {
   const uint32_t c = first + blockIdx.x;
   double* sw = d.sw + size_t(c) * d.Tcap;
   for (uint32_t t = threadIdx.x; t < Tcur; t += blockDim.x) {
-    double mu[3], sd[3];
-    load_control(d, t, mu, sd);
+    double mu[3], sd[3], ld;
+    load_control(d, t, mu, sd, ld);
     const size_t ri = size_t(c) * d.Tcap + t;
-    const double lp = control_log_pdf(mu, sd, Pose{d.relx[ri], d.rely[ri], d.relth[ri]});
+    const double lp = control_log_pdf(mu, sd, ld, Pose{d.relx[ri], d.rely[ri], d.relth[ri]});
+    d.clp[ri] = lp;
     sw[t] = edge_weight_from_log_pdf(lp, 3.0, nullptr);
   }
   build_tree_levels(sw, Tcur);

@@ -99,22 +99,23 @@ MG_DEV Pose control_inv_observe(const double v[3]) {
 }
 
 // log pdf of an independent 3-normal, constants subtracted term by term
-MG_DEV double normal3_log_pdf(const double mu[3], const double sd[3], const double x[3]) {
+// (log_det = log sd[0] + log sd[1] + log sd[2], which the caller keeps per control)
+MG_DEV double normal3_log_pdf(const double mu[3], const double sd[3], double log_det, const double x[3]) {
   const double z0 = (x[0] - mu[0]) / sd[0];
   const double z1 = (x[1] - mu[1]) / sd[1];
   const double z2 = (x[2] - mu[2]) / sd[2];
   const double exponent = -0.5 * (z0 * z0 + z1 * z1 + z2 * z2);
   const double log_root_two_pi = 0.5 * log(2 * kPi);
-  const double log_det = log(sd[0]) + log(sd[1]) + log(sd[2]);
   return exponent - 3 * log_root_two_pi - log_det;
 }
 
 // log pdf of the control model at a pose increment
-MG_DEV double control_log_pdf(const double mu[3], const double sd[3], const Pose& dp) {
+MG_DEV double control_log_pdf(const double mu[3], const double sd[3], double log_det, const Pose& dp) {
   double v[3];
   control_observe(dp, v);
-  return normal3_log_pdf(mu, sd, v);
+  return normal3_log_pdf(mu, sd, log_det, v);
 }
+MG_DEV double control_log_det(double sd0, double sd1, double sd2) { return log(sd0) + log(sd1) + log(sd2); }
 
 // ---- range-only observation model ------------------------------------------
 MG_DEV double range_log_pdf(double mu, double sd, double r) {
@@ -178,7 +179,13 @@ MG_DEV uint32_t suffix_mask(uint32_t i) {
   i |= i >> 16;
   return i;
 }
-MG_DEV uint32_t child_containing(uint32_t p, uint32_t i) { return i & ~(suffix_mask(p ^ i) >> 1); }
+MG_DEV uint32_t child_containing(uint32_t p, uint32_t i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return i & ~((0x7FFFFFFFu >> __clz(int(p ^ i))));  // suffix_mask(x) >> 1 of a non-zero x
+#else
+  return i & ~(suffix_mask(p ^ i) >> 1);
+#endif
+}
 
 // Where a tree's nodes live.  Plain: an array in global memory.  Cached: the same array, with a copy
 // in LDS of every node whose index is a multiple of 2^shift -- the nodes a descent probes first

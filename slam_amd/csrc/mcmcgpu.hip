@@ -242,6 +242,8 @@ int lay_out(mcmcgpu_handle h, bool with_slack) {
     HIP_TRY(h, up(d.csd + size_t(i) * d.Tcap, row.data(), size_t(T) * sizeof(double)));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
   }
+  if (T) control_log_det_kernel<<<(T + 255) / 256, 256, 0, h->stream>>>(d, T);
+  HIP_TRY(h, hipGetLastError());
   // readings: arrival order -> slots, time-sorted inside a landmark
   std::vector<uint32_t> toff(size_t(T) + 2, 0), fill(h->f_start.begin(), h->f_start.end() - 1), tobs(N), ffirst(F, 0),
       opiv(size_t(S) / 32 + 1, 0);
@@ -566,6 +568,7 @@ int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out) {
   } while (0)
   ALLOC(d.cmu, 3 * size_t(d.Tcap));
   ALLOC(d.csd, 3 * size_t(d.Tcap));
+  ALLOC(d.cld, d.Tcap);
   ALLOC(d.foff, size_t(d.Fcap) + 1);
   ALLOC(d.orec, d.Ncap);
   ALLOC(d.osr, d.Ncap);
@@ -590,6 +593,7 @@ int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out) {
   ALLOC(d.relx, C * d.Tcap);
   ALLOC(d.rely, C * d.Tcap);
   ALLOC(d.relth, C * d.Tcap);
+  ALLOC(d.clp, C * d.Tcap);
   ALLOC(d.pxy, C * (size_t(d.Tcap) + 1));
   ALLOC(d.pth, C * (size_t(d.Tcap) + 1));
   ALLOC(d.sw, C * d.Tcap);

@@ -19,6 +19,48 @@ NAMES = ["select+propose", "state: landmark set-up", "state: reading stream", "l
          "reduce + accept", "commit", "whole kernel", "-"]
 
 
+def plaza(a):
+    """One chain, --mcmc-steps 10 --mcmc-end-steps 1000 over the whole log, as bench.py times it."""
+    import subprocess
+    import tempfile
+    import time
+
+    import numpy as np
+
+    from slam_amd import dataset_cache
+    data_dir = os.path.join(ROOT, "tests", "golden", "plaza")
+    exe = os.path.join(ROOT, "slam_amd", "host", "slam_hip")
+    with tempfile.TemporaryDirectory() as tmp:
+        cache = os.path.join(tmp, a.plaza + ".slamro")
+        subprocess.check_call([exe, "--dataset", a.plaza, "--dataset-dir", data_dir, "--dataset-cache", cache,
+                               "--dump-loader"], stdout=subprocess.DEVNULL)
+        data = dataset_cache.read(cache)
+    T, N = data["T"], data["N"]
+    ctrl_mean, ctrl_std = synthetic.control_models(data["controls"], data["dt"])
+    obs_f, order = dataset_cache.dense_landmarks(data["obs_id"])
+    seeds = capi.seed_sequence(42, 6)
+    g = capi.McmcGpu(1, T, len(order), N, threads_per_chain=a.threads_per_chain)
+    g.upload_problem(ctrl_mean, ctrl_std, data["obs_t"], obs_f, data["obs_range"], np.full(N, 1.0), len(order))
+    g.init_chains(np.array([seeds[2]], dtype=np.uint32), capi.uniform_sequence(int(seeds[1]), len(order)))
+    g.debug_phase_cycles(reset=True)
+    t0 = time.perf_counter()
+    g.advance(T, steps_per_timestep=10, end_steps=1000)
+    g.sync()
+    wall = time.perf_counter() - t0
+    cyc = g.debug_phase_cycles()
+    u = g.counters()
+    s = g.traffic_counters()
+    nprop, nacc, units = int(u[0][0]), int(u[1][0]), int(u[2][0])
+    whole = float(cyc[6])
+    print(f"{a.plaza}: {T} timesteps, {N} readings, wall {wall:.3f} s, {nprop} updates ({int(s[0][0])} state edges), "
+          f"{nacc} accepted, {units / max(nprop, 1):.0f} units per update, {int(s[1][0]) / max(nacc, 1):.0f} poses moved per accept")
+    print(f"whole kernel {whole / 1e6:.1f} Mcycles = {whole / max(nprop, 1):.0f} cycles per update")
+    for i in range(6):
+        print(f"  {NAMES[i]:28s} {100.0 * cyc[i] / whole:6.2f} % of kernel   {cyc[i] / max(nprop, 1):10.0f} cycles per update")
+    rest = whole - float(cyc[:6].sum())
+    print(f"  {'growth and the rest':28s} {100.0 * rest / whole:6.2f} % of kernel   {rest / max(nprop, 1):10.0f} cycles per update")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--chains", type=int, default=1024)
@@ -26,7 +68,10 @@ def main():
     ap.add_argument("--timesteps", type=int, default=100_000)
     ap.add_argument("--landmarks", type=int, default=1000)
     ap.add_argument("--threads-per-chain", type=int, default=0)
+    ap.add_argument("--plaza", default="", help="Plaza1 or Plaza2: the online replay of bench.py's plaza line instead")
     a = ap.parse_args()
+    if a.plaza:
+        return plaza(a)
     p = synthetic.make_problem(T=a.timesteps, n_landmarks=a.landmarks)
     g = capi.McmcGpu(a.chains, p["T"], p["F"], p["N"], threads_per_chain=a.threads_per_chain)
     g.upload_problem(p["ctrl_mean"], p["ctrl_std"], p["obs_t"], p["obs_f"], p["obs_mean"], p["obs_std"], p["F"])
