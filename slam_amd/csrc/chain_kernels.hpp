@@ -75,6 +75,7 @@ struct Dev {
   const double* osd;          // [Ncap] std deviation of a reading
   const double* oisd;         // [Ncap] 1 / std deviation
   const uint32_t* opiv;       // [Ncap/32+1] timestep of every 32nd reading (search pivots)
+  const uint32_t* otime;      // [Ncap] timestep of every reading (32 to a cache line, for searches)
   // [tblk_rows][Fcap] landmark f against the block of timesteps [b << tblk_shift, (b + 1) << tblk_shift),
   // for the blocks b = 0 .. tblk_n - 1 that the last layout of the problem covered; row tblk_n holds
   // the readings before the end of the last block.  Block-major: one proposal asks for the same
@@ -108,8 +109,9 @@ struct Dev {
   uint32_t* fpt;                // [C][Fcap]   parent timestep
   // [C][Fcap] the parent's world pose: a copy of pose-table entry fpt, rewritten by the same
   // arithmetic whenever that entry is, so a proposal reads its landmarks' parents with neighbouring
-  // lanes on neighbouring addresses instead of one scattered table line per landmark
-  double *fpx, *fpy, *fpth;
+  // lanes on neighbouring addresses instead of one scattered table line per landmark; with it the
+  // cosine and sine of its angle (taken anew whenever the angle changes)
+  double *fpx, *fpy, *fpth, *fpc, *fps;
   uint32_t* flast;              // [C][Fcap]   timestep of the latest reading seen
   uint32_t* nf;                 // [C]         landmarks known
   double* ll;                   // [C]         chain log likelihood
@@ -269,13 +271,16 @@ MG_DEV Pose world_pose(const Dev& d, uint32_t c, uint32_t k) {
 }
 
 // The parent pose of landmark entry fi = c * Fcap + f, from its copy beside the landmark.
-MG_DEV Pose parent_pose(const Dev& d, size_t fi) { return Pose{d.fpx[fi], d.fpy[fi], d.fpth[fi]}; }
+MG_DEV Frame parent_frame(const Dev& d, size_t fi) { return Frame{d.fpx[fi], d.fpy[fi], d.fpc[fi], d.fps[fi]}; }
 // Takes the copy anew from the pose table (the landmark got a parent, or the table was rebuilt).
 MG_DEV void keep_parent_pose(const Dev& d, uint32_t c, size_t fi, uint32_t pt) {
   const Pose p = world_pose(d, c, pt);
+  const Frame f = frame_of(p);
   d.fpx[fi] = p.x;
   d.fpy[fi] = p.y;
   d.fpth[fi] = p.th;
+  d.fpc[fi] = f.c;
+  d.fps[fi] = f.s;
 }
 
 // Appends pose Tcur+1 = P[Tcur] o rel (lane 0, graph growth).
@@ -733,7 +738,7 @@ MG_DEV double eval_feature_edge(const Dev& d, uint32_t c, Shared& S, uint32_t f,
                                 unsigned long long& units) {
   const size_t fi = size_t(c) * d.Fcap + f;
   if (threadIdx.x == 0) {
-    const Pose Pp = parent_pose(d, fi);
+    const Frame Pp = parent_frame(d, fi);
     const Vec2 wo = act(Pp, Vec2{d.fex[fi], d.fey[fi]});
     const Vec2 wn = act(Pp, e_new);
     S.seglo[0] = d.foff[f];
@@ -790,14 +795,41 @@ MG_DEV uint32_t split_readings(const Dev& d, uint32_t f, uint32_t lo, uint32_t h
     if (pa > pa0) a = (pa - 1) << 5;  // reading 32*(pa-1) is <= t
     if ((pa << 5) < b) b = pa << 5;   // reading 32*pa is > t
   }
+  // what is left spans a few lines of the timestep array: ask for them together, then search
+  if (b - a > 32) {
+    uint32_t touch = 0;
+    for (uint32_t j = a + 32; j < b; j += 32) touch += d.otime[j];
+    asm volatile("" ::"v"(touch));
+  }
   while (a < b) {
     const uint32_t m = (a + b) >> 1;
-    if (d.orec[m].t <= t)
+    if (d.otime[m] <= t)
       a = m + 1;
     else
       b = m;
   }
   return a;
+}
+
+// The four rigid motions of a state-edge proposal, each with the cosine and sine of its angle: poses
+// t and t + 1, the proposed relative pose and its inverse.  The four sincos evaluations are
+// independent, so lanes 4k .. 4k+3 of every wavefront take one each and exchange the results.
+struct ProposalFrames {
+  Frame Pt, Pt1, q, qinv;
+};
+MG_DEV ProposalFrames proposal_frames(const Pose& Pt, const Pose& Pt1, const Pose& q) {
+  const uint32_t which = threadIdx.x & 3u;
+  const double angle = which == 0 ? Pt.th : which == 1 ? Pt1.th : which == 2 ? q.th : -q.th;
+  double sn, cs;
+  sincos(angle, &sn, &cs);
+  double c[4], s[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    c[k] = __shfl(cs, k, 4);
+    s[k] = __shfl(sn, k, 4);
+  }
+  return ProposalFrames{Frame{Pt.x, Pt.y, c[0], s[0]}, Frame{Pt1.x, Pt1.y, c[1], s[1]}, Frame{q.x, q.y, c[2], s[2]},
+                        inverse_frame(q, c[3], s[3])};
 }
 
 // State edge (mcmc_slam.hpp:432-466), observation part only.  Replacing the
@@ -811,13 +843,69 @@ MG_DEV double eval_state_edge(const Dev& d, uint32_t c, Shared& S, uint32_t t, c
                               unsigned long long& units) {
   const uint32_t tid = threadIdx.x, nthr = blockDim.x;
   const uint32_t segcap = nthr < uint32_t(kMaxSeg) ? nthr : uint32_t(kMaxSeg);
-  const Pose Pt = world_pose(d, c, t), Pt1 = world_pose(d, c, t + 1);
-  const Pose qinv = inverse(q);
+  const ProposalFrames fr = proposal_frames(world_pose(d, c, t), world_pose(d, c, t + 1), q);
   const size_t fbase = size_t(c) * d.Fcap;
   double acc = 0.0;
 #ifdef MG_PHASE_TIMING
   long long tab = clock64();
 #endif
+  // B: one lane per landmark with affected readings: split its reading list at t, move it
+  auto prepare = [&](uint32_t f, bool affected) -> uint32_t {
+    const uint32_t lo = d.foff[f];
+    uint32_t slo = lo, len = 0;
+    Vec2 w{0.0, 0.0}, wn{0.0, 0.0};
+    if (affected) {
+      const uint32_t hi = lo + d.fcnt[fbase + f];
+      const uint32_t pt = d.fpt[fbase + f];
+      const Vec2 e{d.fex[fbase + f], d.fey[fbase + f]};
+      const Frame Pp = parent_frame(d, fbase + f);
+      const uint32_t a = split_readings(d, f, lo, hi, t);
+      w = act(Pp, e);
+      uint32_t shi;
+      if (t < pt) {  // landmark hangs off a pose that moves
+        wn = act(fr.Pt, act(fr.q, act_inverse(fr.Pt1, w)));
+        slo = lo;
+        shi = a;
+      } else {  // poses after t move, seen from them the landmark moves by the inverse
+        wn = act(fr.Pt1, act(fr.qinv, act_inverse(fr.Pt, w)));
+        slo = a;
+        shi = hi;
+      }
+      len = shi - slo;
+    }
+    S.seglo[tid] = slo;
+    S.segw[tid][0] = w.x;
+    S.segw[tid][1] = w.y;
+    S.segw[tid][2] = wn.x;
+    S.segw[tid][3] = wn.y;
+    return len;
+  };
+  auto stream = [&](uint32_t len, uint32_t nseg) {
+    uint32_t total;
+    const uint32_t incl = block_scan_u32(len, S, total);
+    if (tid < nseg) S.segpre[tid + 1] = incl;
+    if (tid == 0) S.segpre[0] = 0;
+    __syncthreads();
+    units += total;
+    MG_STAMP(tc0);
+    MG_PHASE_ADD(S, 1, tab, tc0);
+    // C: stream the affected readings
+    acc += eval_ratio<RB>(d, c, S, nseg);
+    __syncthreads();
+    MG_STAMP(tc1);
+    MG_PHASE_ADD(S, 2, tc0, tc1);
+#ifdef MG_PHASE_TIMING
+    tab = tc1;
+#endif
+  };
+  if (nf <= segcap) {
+    // few landmarks: every one is a segment, those without affected readings an empty one (the
+    // readings come in the same order as below, so the sums are the same)
+    uint32_t len = 0;
+    if (tid < nf) len = prepare(tid, d.ffirst[tid] <= t && t < d.flast[fbase + tid]);
+    stream(len, nf);
+    return block_sum(acc, S);
+  }
   const uint32_t per = uint32_t(kActCap) / nthr;  // landmarks examined per lane and round (1..16)
   for (uint32_t f0 = 0; f0 < nf; f0 += uint32_t(kActCap)) {
     // A: which landmarks have affected readings?  first <= t < last
@@ -837,50 +925,9 @@ MG_DEV double eval_state_edge(const Dev& d, uint32_t c, Shared& S, uint32_t t, c
     __syncthreads();
     for (uint32_t a0 = 0; a0 < nact; a0 += segcap) {
       const uint32_t nseg = (nact - a0) < segcap ? (nact - a0) : segcap;
-      // B: one lane per active landmark: split its reading list at t, move it
       uint32_t len = 0;
-      if (tid < nseg) {
-        const uint32_t f = S.act[a0 + tid];
-        const uint32_t lo = d.foff[f], hi = lo + d.fcnt[fbase + f];
-        const uint32_t pt = d.fpt[fbase + f];
-        const Vec2 e{d.fex[fbase + f], d.fey[fbase + f]};
-        const Pose Pp = parent_pose(d, fbase + f);
-        const uint32_t a = split_readings(d, f, lo, hi, t);
-        const Vec2 w = act(Pp, e);
-        Vec2 wn;
-        uint32_t slo, shi;
-        if (t < pt) {  // landmark hangs off a pose that moves
-          wn = act(Pt, act(q, act_inverse(Pt1, w)));
-          slo = lo;
-          shi = a;
-        } else {  // poses after t move, seen from them the landmark moves by the inverse
-          wn = act(Pt1, act(qinv, act_inverse(Pt, w)));
-          slo = a;
-          shi = hi;
-        }
-        S.seglo[tid] = slo;
-        S.segw[tid][0] = w.x;
-        S.segw[tid][1] = w.y;
-        S.segw[tid][2] = wn.x;
-        S.segw[tid][3] = wn.y;
-        len = shi - slo;
-      }
-      uint32_t total;
-      const uint32_t incl = block_scan_u32(len, S, total);
-      if (tid < nseg) S.segpre[tid + 1] = incl;
-      if (tid == 0) S.segpre[0] = 0;
-      __syncthreads();
-      units += total;
-      MG_STAMP(tc0);
-      MG_PHASE_ADD(S, 1, tab, tc0);
-      // C: stream the affected readings
-      acc += eval_ratio<RB>(d, c, S, nseg);
-      __syncthreads();
-      MG_STAMP(tc1);
-      MG_PHASE_ADD(S, 2, tc0, tc1);
-#ifdef MG_PHASE_TIMING
-      tab = tc1;
-#endif
+      if (tid < nseg) len = prepare(S.act[a0 + tid], true);
+      stream(len, nseg);
     }
   }
   return block_sum(acc, S);
@@ -913,6 +960,26 @@ MG_DEV void move_pose(const Dev& d, size_t i, const PoseMove& m) {
   d.pxy[i] = moved(m, d.pxy[i]);
   d.pth[i] += m.dth;
 }
+// Poses base + k for k = first, first + stride, ... below `end`: four per lane are loaded before the
+// first is stored, so a lane waits for memory once per four poses.
+MG_DEV void move_poses(const Dev& d, size_t base, uint32_t first, uint32_t end, uint32_t stride, const PoseMove& m) {
+  uint32_t k = first;
+  for (; k < end && end - k > 3 * stride; k += 4 * stride) {
+    PoseXY p[4];
+    double th[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      p[u] = d.pxy[base + k + u * stride];
+      th[u] = d.pth[base + k + u * stride];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      d.pxy[base + k + u * stride] = moved(m, p[u]);
+      d.pth[base + k + u * stride] = th[u] + m.dth;
+    }
+  }
+  for (; k < end; k += stride) move_pose(d, base + k, m);
+}
 // The copies of parent poses after edge t move exactly as their table entries do (all lanes).
 MG_DEV void move_parent_poses(const Dev& d, uint32_t c, uint32_t t, uint32_t nf, const PoseMove& m) {
   const size_t fbase = size_t(c) * d.Fcap;
@@ -920,9 +987,14 @@ MG_DEV void move_parent_poses(const Dev& d, uint32_t c, uint32_t t, uint32_t nf,
     const size_t fi = fbase + f;
     if (d.fpt[fi] > t) {
       const PoseXY p = moved(m, PoseXY{d.fpx[fi], d.fpy[fi]});
+      const double th = d.fpth[fi] + m.dth;
+      double sn, cs;
+      sincos(th, &sn, &cs);
       d.fpx[fi] = p.x;
       d.fpy[fi] = p.y;
-      d.fpth[fi] += m.dth;
+      d.fpth[fi] = th;
+      d.fpc[fi] = cs;
+      d.fps[fi] = sn;
     }
   }
 }
@@ -930,7 +1002,7 @@ MG_DEV void commit_state_edge(const Dev& d, uint32_t c, uint32_t t, const Pose& 
   const size_t base = size_t(c) * (d.Tcap + 1);
   const PoseMove m = pose_move_of(d, c, t, q);
   __syncthreads();  // every lane holds the old pivot before anything is overwritten
-  for (uint32_t k = t + 1 + threadIdx.x; k <= Tcur; k += blockDim.x) move_pose(d, base + k, m);
+  move_poses(d, base, t + 1 + threadIdx.x, Tcur + 1, blockDim.x, m);
   move_parent_poses(d, c, t, nf, m);
 }
 
@@ -1166,7 +1238,7 @@ MG_DEV bool driver_arrival(const Dev& d, uint32_t c, Shared& S, uint32_t o) {
   const uint32_t rel = o - d.foff[f];
   d.fcnt[fi] = rel + 1;
   d.flast[fi] = t;
-  const Vec2 w = act(parent_pose(d, fi), Vec2{d.fex[fi], d.fey[fi]});
+  const Vec2 w = act(parent_frame(d, fi), Vec2{d.fex[fi], d.fey[fi]});
   const Vec2 est = act_inverse(world_pose(d, c, t), w);
   S.ll += reading_log_pdf(m, est);
   const double par_mu = d.orec[d.foff[f] + d.fpar[fi]].mu;
@@ -1584,7 +1656,7 @@ __global__ void split_commit_kernel(Dev d_by_value, uint32_t Tcur) {
   const size_t base = size_t(c) * (d.Tcap + 1);
   const uint32_t n = Tcur - from + 1, per = (n + gridDim.x - 1) / gridDim.x;
   const uint32_t lo = from + blockIdx.x * per, hi = min(Tcur + 1, lo + per);
-  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) move_pose(d, base + i, m);
+  move_poses(d, base, lo + threadIdx.x, hi, blockDim.x, m);
 }
 
 // Landmark f of chain c under the proposal in `k`: first record and number of its affected readings,
@@ -1601,7 +1673,7 @@ MG_DEV uint32_t split_setup_landmark(const Dev& d, uint32_t c, uint32_t f, const
       const Pose Pt = world_pose(d, c, t), Pt1 = world_pose(d, c, t + 1);
       const uint32_t lo = d.foff[f], hi = lo + d.fcnt[fi], pt = d.fpt[fi];
       const uint32_t a = split_readings(d, f, lo, hi, t);
-      w = act(parent_pose(d, fi), Vec2{d.fex[fi], d.fey[fi]});
+      w = act(parent_frame(d, fi), Vec2{d.fex[fi], d.fey[fi]});
       if (t < pt) {
         wn = act(Pt, act(q, act_inverse(Pt1, w)));
         slo = lo;
@@ -1613,7 +1685,7 @@ MG_DEV uint32_t split_setup_landmark(const Dev& d, uint32_t c, uint32_t f, const
       }
     }
   } else if (k.op == OP_EVAL_FEATURE && f == k.idx) {
-    const Pose Pp = parent_pose(d, fi);
+    const Frame Pp = parent_frame(d, fi);
     w = act(Pp, Vec2{d.fex[fi], d.fey[fi]});
     wn = act(Pp, Vec2{k.q[0], k.q[1]});
     len = d.fcnt[fi];
@@ -2090,6 +2162,7 @@ __global__ void append_kernel(Dev d, AppendArgs a) {
     }
     const_cast<uint32_t*>(d.tobs)[a.arrival0 + i] = s;
     if ((s & 31u) == 0) const_cast<uint32_t*>(d.opiv)[s >> 5] = a.t;
+    const_cast<uint32_t*>(d.otime)[s] = a.t;
     if (a.is_new[i]) {
       const_cast<uint32_t*>(d.foff)[f] = s;
       const_cast<uint32_t*>(d.ffirst)[f] = a.t;
@@ -2118,6 +2191,7 @@ __global__ void move_list_kernel(Dev d, uint32_t f, uint32_t from, uint32_t to, 
       const_cast<double*>(d.obisd)[s] = d.obisd[from + i];
     }
     if ((s & 31u) == 0) const_cast<uint32_t*>(d.opiv)[s >> 5] = r.t;
+    const_cast<uint32_t*>(d.otime)[s] = r.t;
     for (uint32_t a = d.toff[r.t]; a < d.toff[r.t + 1]; ++a)
       if (d.tobs[a] == from + i) {
         const_cast<uint32_t*>(d.tobs)[a] = s;

@@ -65,6 +65,27 @@ MG_DEV Vec2 act_inverse(const Pose& p, const Vec2& v) {
   return Vec2{c * dx + s * dy, c * dy - s * dx};
 }
 
+// A pose together with the cosine and sine of its angle: what act / act_inverse above compute
+// first, kept so that transforming many points by one pose takes the pair once.  Same arithmetic.
+struct Frame {
+  double x, y, c, s;
+};
+MG_DEV Frame frame_of(const Pose& p) {
+  Frame f{p.x, p.y, 0.0, 0.0};
+  sincos(p.th, &f.s, &f.c);
+  return f;
+}
+MG_DEV Vec2 act(const Frame& p, const Vec2& v) { return Vec2{p.x + (p.c * v.x - p.s * v.y), p.y + (p.s * v.x + p.c * v.y)}; }
+MG_DEV Vec2 act_inverse(const Frame& p, const Vec2& v) {
+  const double dx = v.x - p.x, dy = v.y - p.y;
+  return Vec2{p.c * dx + p.s * dy, p.c * dy - p.s * dx};
+}
+// inverse(q) as a frame, from the cosine and sine of -q.th
+MG_DEV Frame inverse_frame(const Pose& q, double c, double s) {
+  const double nx = -q.x, ny = -q.y;
+  return Frame{c * nx - s * ny, s * nx + c * ny, c, s};
+}
+
 MG_DEV double wrap_angle(double a) {
   // fmod leaves an argument below the modulus as it is; almost every angle here is one, and the
   // general fmod is a long loop on this hardware

@@ -298,6 +298,7 @@ int lay_out(mcmcgpu_handle h, bool with_slack) {
   HIP_TRY(h, up(d.osr, osr.data(), size_t(S) * sizeof(StreamRec)));
   HIP_TRY(h, up(d.oisd, oisd.data(), size_t(S) * sizeof(double)));
   HIP_TRY(h, up(d.opiv, opiv.data(), opiv.size() * sizeof(uint32_t)));
+  HIP_TRY(h, up(d.otime, h->h_ot.data(), size_t(S) * sizeof(uint32_t)));
   HIP_TRY(h, up(d.tobs, tobs.data(), size_t(N) * sizeof(uint32_t)));
   HIP_TRY(h, up(d.osd, osd.data(), size_t(S) * sizeof(double)));
   HIP_TRY(h, up(d.ffirst, ffirst.data(), size_t(F) * sizeof(uint32_t)));
@@ -574,6 +575,7 @@ int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out) {
   ALLOC(d.osr, d.Ncap);
   ALLOC(d.oisd, d.Ncap);
   ALLOC(d.opiv, size_t(d.Ncap) / 32 + 2);
+  ALLOC(d.otime, d.Ncap);
   d.tblk_shift = kTimeBlockShift;
   d.tblk_rows = (d.Tcap >> kTimeBlockShift) + 3;
   d.tblk_n = 0;
@@ -606,6 +608,8 @@ int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out) {
   ALLOC(d.fpx, C * d.Fcap);
   ALLOC(d.fpy, C * d.Fcap);
   ALLOC(d.fpth, C * d.Fcap);
+  ALLOC(d.fpc, C * d.Fcap);
+  ALLOC(d.fps, C * d.Fcap);
   ALLOC(d.flast, C * d.Fcap);
   ALLOC(d.nf, C);
   ALLOC(d.ll, C);
