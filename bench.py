@@ -72,6 +72,9 @@ def parse_args():
     ap.add_argument("--split-slices", type=int, default=0,
                     help="run every update as a sequence of kernels with each proposal's reading stream cut into "
                          "this many workgroups (mcmcgpu_run_split): for few, long chains")
+    ap.add_argument("--collectives-with-one-rank", action="store_true",
+                    help="testing aid: with one rank, still set up an RCCL process group of that one rank and "
+                         "run every exchange through it")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="testing aid: all ranks share GPU 0 and exchange over gloo (RCCL refuses two ranks on one "
                          "device); exercises the N > 1 code path on a one-GPU box, its numbers mean nothing")
@@ -229,6 +232,13 @@ def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(launch_ranks(args.gpus))
+    # Libraries write to the process's standard output behind Python's back (RCCL prints a version
+    # banner there when a communicator is made).  The JSON line is the only thing this program may
+    # print there, so file descriptor 1 points at standard error from here on and the line goes to a
+    # duplicate of the original descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -252,6 +262,13 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    elif args.collectives_with_one_rank:
+        import socket
+
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
 
     tempering = args.workload == "tempering"
     bearing = args.workload == "range-bearing"
@@ -301,7 +318,7 @@ def main():
         return gathered[-1], torch.max(gathered[:, :, 0], dim=1).values
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -457,8 +474,8 @@ def main():
             g.close()
             out["plaza1"] = plaza_wall("Plaza1", local_rank, with_cpu=not args.no_cpu_baseline)
             out["plaza2"] = plaza_wall("Plaza2", local_rank, with_cpu=not args.no_cpu_baseline)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -13,6 +13,13 @@ import torch
 import torch.distributed as dist
 
 
+def _alone(world):
+    """True when there is nobody to exchange with.  A process group of ONE rank that has been set up
+    anyway (bench.py --collectives-with-one-rank: the only way to run the RCCL calls on a one-GPU
+    machine) still goes through every collective."""
+    return world == 1 and not dist.is_initialized()
+
+
 def _host_staged(group=None):
     """gloo moves host memory only; device tensors are staged through the host for it (the CPU
     tests, and rehearsals of the multi-rank path on one GPU).  RCCL takes device memory as is."""
@@ -34,7 +41,7 @@ def shard_seeds(all_seeds, chains_per_rank, rank):
 def gather_summaries(local, world, group=None):
     """local: [C, 2] float64 tensor of mcmcgpu_chain_summary records (column 0 = log
     likelihood).  Returns the [world*C, 2] tensor of all ranks, in global chain order."""
-    if world == 1:
+    if _alone(world):
         return local
     if local.is_cuda and _host_staged(group):
         return gather_summaries(local.cpu(), world, group).to(local.device)
@@ -59,7 +66,7 @@ def best_chain(all_summaries, chains_per_rank):
 
 def broadcast_from_owner(buf, owner, world, group=None):
     """Broadcast of the winner's packed state (relative poses + landmark estimates)."""
-    if world > 1:
+    if not _alone(world):
         if buf.is_cuda and _host_staged(group):
             host = buf.cpu()
             dist.broadcast(host, src=owner, group=group)
@@ -71,7 +78,7 @@ def broadcast_from_owner(buf, owner, world, group=None):
 
 def all_reduce(t, op, world, group=None):
     """In-place all-reduce of a tensor on any backend."""
-    if world > 1:
+    if not _alone(world):
         if t.is_cuda and _host_staged(group):
             host = t.cpu()
             dist.all_reduce(host, op=op, group=group)

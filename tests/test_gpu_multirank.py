@@ -68,3 +68,21 @@ def test_bench_starts_its_own_ranks(tmp_path):
     line = [x for x in out.stdout.splitlines() if x.startswith("{")][-1]
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["config"]["chains_total"] == 16 and rec["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_exchanges_through_rccl_and_prints_one_line():
+    """The bench with a process group of one rank on the "nccl" backend: every exchange of a step (all-gather
+    of the report records, barrier, broadcast of the winner, all-reduces of the totals) goes through RCCL on
+    device buffers, and standard output carries the JSON line and nothing else (RCCL's banner goes to stderr)."""
+    import json
+
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--collectives-with-one-rank", "--steps", "2",
+                          "--warmup", "1", "--timesteps", "3000", "--landmarks", "40", "--k-nearest", "4", "--chains", "8",
+                          "--updates-per-step", "100", "--no-cpu-baseline", "--no-plaza"],
+                         capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [x for x in out.stdout.splitlines() if x.strip()]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["config"]["chains_total"] == 8 and rec["value"] > 0
