@@ -425,8 +425,12 @@ void mcmcgpu_uniform_sequence(uint32_t seed, uint32_t n, double* out);
  * chain spent per phase of the advance kernel, summed over chains -- [0] serial
  * selection/proposal, [1] state edge: landmark set-up, [2] state edge: reading
  * stream, [3] landmark edge evaluation, [4] reduction + accept test, [5] commit,
- * [6] whole kernel.  A normal build returns MCMCGPU_ERR_STATE. */
-int mcmcgpu_debug_phase_cycles(mcmcgpu_handle h, uint64_t out[8], int reset);
+ * [6] whole kernel, [7] SIMD of the driver's wavefront (four 16-bit counters);
+ * inside [0], for state edges: [8] weight totals, [9] the uniform that picks the
+ * tree, [10] tree descent, [11] three normals, [12] inv_observe, [13] control log
+ * density; [14] a landmark proposal from the descent on.  A normal build returns
+ * MCMCGPU_ERR_STATE. */
+int mcmcgpu_debug_phase_cycles(mcmcgpu_handle h, uint64_t out[16], int reset);
 
 /* Test hook for the scan building block: inclusive prefix "sums" of n affine
  * maps x -> a + b*x (mod p) under composition, computed by the same wavefront

@@ -508,7 +508,7 @@ class McmcGpu:
             "mcmcgpu_load_state")
 
     def debug_phase_cycles(self, reset=True):
-        out = np.zeros(8, dtype=np.uint64)
+        out = np.zeros(16, dtype=np.uint64)
         self._check(self.lib.mcmcgpu_debug_phase_cycles(self.h, _ptr(out), ctypes.c_int(1 if reset else 0)),
                     "mcmcgpu_debug_phase_cycles")
         return out

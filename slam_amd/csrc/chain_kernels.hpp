@@ -209,14 +209,24 @@ enum Stage : int { ST_EDGE = 0, ST_ARRIVALS = 1, ST_STEPS = 2, ST_NEXT = 3, ST_E
   do {                                                  \
     if (threadIdx.x == 0) (S).phase[slot] += (b) - (a); \
   } while (0)
-__device__ unsigned long long g_phase_cycles[8];
+// inside lane 0's serial code: time since the last mark goes to `slot`
+#define MG_MARK_BEGIN() long long mark_last_ = clock64()
+#define MG_MARK(S, slot)                      \
+  do {                                        \
+    const long long now_ = clock64();         \
+    (S).phase[slot] += now_ - mark_last_;     \
+    mark_last_ = now_;                        \
+  } while (0)
+__device__ unsigned long long g_phase_cycles[16];
 #else
 #define MG_STAMP(v)
 #define MG_PHASE_ADD(S, slot, a, b)
+#define MG_MARK_BEGIN()
+#define MG_MARK(S, slot)
 #endif
 
 struct Shared {
-  long long phase[8];
+  long long phase[16];
   RngState rng;
   // driver state (lane 0 only)
   int stage;
@@ -1105,11 +1115,15 @@ MG_DEV void refresh_totals(const Dev& d, uint32_t c, Shared& S) {
 // Returns false when nothing can be updated (both weight totals zero, :345).
 MG_DEV bool driver_begin_update(const Dev& d, uint32_t c, Shared& S) {
   const wt::Cached sw = state_tree(d, c, S), fw = landmark_tree(d, c, S);
+  MG_MARK_BEGIN();
   refresh_totals(d, c, S);
   const double Ws = S.Ws, Wf = S.Wf;
   if (Ws == 0 && Wf == 0) return false;
   uint32_t retry = 0;
-  if ((Ws + Wf) * rng_uniform(S.rng) < Ws) {
+  MG_MARK(S, 8);
+  const double which = rng_uniform(S.rng);
+  MG_MARK(S, 9);
+  if ((Ws + Wf) * which < Ws) {
     uint32_t t;
     do {
       t = wt::search(sw, S.Tcur, Ws * rng_uniform(S.rng));
@@ -1118,15 +1132,19 @@ MG_DEV bool driver_begin_update(const Dev& d, uint32_t c, Shared& S) {
       S.failed = 1;
       return false;
     }
+    MG_MARK(S, 10);
     double mu[3], sd[3], v[3], ld;
     load_control(d, t, mu, sd, ld);
     // the current relative pose's log density is kept from when that pose was set
     const double old_pll = d.clp[size_t(c) * d.Tcap + t];
     for (int i = 0; i < 3; ++i) v[i] = rng_normal(S.rng);
     for (int i = 0; i < 3; ++i) v[i] = v[i] * sd[i] + mu[i];
+    MG_MARK(S, 11);
     const Pose q = control_inv_observe(v);
+    MG_MARK(S, 12);
     S.new_pll = control_log_pdf(mu, sd, ld, q);
     S.old_pll = old_pll;
+    MG_MARK(S, 13);
     S.op = OP_EVAL_STATE;
     S.idx = t;
     S.q[0] = q.x;
@@ -1151,6 +1169,7 @@ MG_DEV bool driver_begin_update(const Dev& d, uint32_t c, Shared& S) {
     S.q[0] = q.x;
     S.q[1] = q.y;
     S.q[2] = 0.0;
+    MG_MARK(S, 14);
   }
   S.pending = PEND_UPDATE;
   S.use_weight = 1;
@@ -1368,7 +1387,7 @@ MG_DEV void chain_state_load(const Dev& d, uint32_t c, Shared& S) {
     S.sw_top = S.fw_top = 0;
     S.sw_shift = S.fw_shift = 0;
     S.pending = PEND_NONE;
-    for (int i = 0; i < 8; ++i) S.phase[i] = 0;
+    for (int i = 0; i < 16; ++i) S.phase[i] = 0;
   }
 }
 MG_DEV void chain_state_store(const Dev& d, uint32_t c, Shared& S) {
@@ -1528,7 +1547,7 @@ __global__ void advance_kernel(Dev d, uint32_t first_tn, uint32_t Tcur0, uint32_
     // (HW_ID register, SIMD_ID = bits 5:4)
     const uint32_t simd = __builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11));
     S.phase[7] = 1ll << (16 * (simd & 3));
-    for (int i = 0; i < 8; ++i) atomicAdd(&g_phase_cycles[i], (unsigned long long)S.phase[i]);
+    for (int i = 0; i < 16; ++i) atomicAdd(&g_phase_cycles[i], (unsigned long long)S.phase[i]);
   }
 #endif
   chain_state_store(d, c, S);

@@ -1885,20 +1885,20 @@ void mcmcgpu_uniform_sequence(uint32_t seed, uint32_t n, double* out) {
   for (uint32_t i = 0; i < n; ++i) out[i] = rng_uniform(r);
 }
 
-int mcmcgpu_debug_phase_cycles(mcmcgpu_handle h, uint64_t out[8], int reset) {
+int mcmcgpu_debug_phase_cycles(mcmcgpu_handle h, uint64_t out[16], int reset) {
   if (!h || !out) return MCMCGPU_ERR_ARGUMENT;
 #ifdef MG_PHASE_TIMING
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
-  HIP_TRY(h, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), 8 * sizeof(uint64_t)));
+  HIP_TRY(h, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), 16 * sizeof(uint64_t)));
   if (reset) {
-    const uint64_t zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const uint64_t zero[16] = {};
     HIP_TRY(h, hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), zero, sizeof zero));
   }
   return 0;
 #else
   (void)reset;
-  for (int i = 0; i < 8; ++i) out[i] = 0;
+  for (int i = 0; i < 16; ++i) out[i] = 0;
   return fail(h, MCMCGPU_ERR_STATE, "library was built without -DMG_PHASE_TIMING");
 #endif
 }

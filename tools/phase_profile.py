@@ -19,6 +19,23 @@ NAMES = ["select+propose", "state: landmark set-up", "state: reading stream", "l
          "reduce + accept", "commit", "whole kernel", "-"]
 
 
+FINE = [(8, "weight totals"), (9, "uniform that picks the tree"), (10, "state tree descent (+ its uniform)"),
+        (11, "three normals"), (12, "inv_observe"), (13, "control log density")]
+
+
+def fine(cyc, nprop, nstate):
+    """Inside selection and proposal: lane-0 cycles per state-edge proposal of each part."""
+    nstate = max(nstate, 1)
+    print("  inside select+propose, per state-edge proposal:")
+    for slot, name in FINE[2:]:
+        print(f"    {name:36s} {cyc[slot] / nstate:10.0f} cycles")
+    print(f"    {'landmark proposal, descent to end':36s} {cyc[14] / max(nprop - nstate, 1):10.0f} cycles per landmark proposal")
+    for slot, name in FINE[:2]:
+        print(f"    {name:36s} {cyc[slot] / max(nprop, 1):10.0f} cycles per update")
+    inside = float(sum(cyc[k] for k in range(8, 15)))
+    print(f"    {'driver state machine, calls, stores':36s} {(float(cyc[0]) - inside) / max(nprop, 1):10.0f} cycles per update")
+
+
 def plaza(a):
     """One chain, --mcmc-steps 10 --mcmc-end-steps 1000 over the whole log, as bench.py times it."""
     import subprocess
@@ -59,6 +76,7 @@ def plaza(a):
         print(f"  {NAMES[i]:28s} {100.0 * cyc[i] / whole:6.2f} % of kernel   {cyc[i] / max(nprop, 1):10.0f} cycles per update")
     rest = whole - float(cyc[:6].sum())
     print(f"  {'growth and the rest':28s} {100.0 * rest / whole:6.2f} % of kernel   {rest / max(nprop, 1):10.0f} cycles per update")
+    fine(cyc, nprop, int(s[0][0]))
 
 
 def main():
@@ -106,6 +124,7 @@ def main():
     launches = 2  # the warm-up launch was reset away; slot 7 counts the timed launch only after the reset
     hist = [(int(cyc[7]) >> (16 * k)) & 0xFFFF for k in range(4)]
     print(f"  driver wavefronts per SIMD id (one per chain and launch): {hist}")
+    fine(cyc, nprop, nstate)
 
 
 if __name__ == "__main__":
