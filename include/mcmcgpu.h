@@ -43,7 +43,7 @@ typedef struct mcmcgpu_config {
   uint32_t max_timesteps;     /* capacity for controls (state edges) */
   uint32_t max_features;      /* capacity for landmarks */
   uint32_t max_observations;  /* capacity for range readings */
-  uint32_t threads_per_chain; /* workgroup size; 0 -> 256; multiple of 64, <= 1024 */
+  uint32_t threads_per_chain; /* workgroup size; 0 -> 256 (128 when max_observations <= 4096); power of two in [64, 1024] */
   /* Order of the two draws inside a landmark proposal.  The reference leaves it
    * unsequenced (src/planar_robot/range_bearing_model.hpp:155-159): 1 = uniform
    * then normal (what g++ emits), 0 = normal then uniform (clang). */
@@ -428,7 +428,8 @@ void mcmcgpu_uniform_sequence(uint32_t seed, uint32_t n, double* out);
  * [6] whole kernel, [7] SIMD of the driver's wavefront (four 16-bit counters);
  * inside [0], for state edges: [8] weight totals, [9] the uniform that picks the
  * tree, [10] tree descent, [11] three normals, [12] inv_observe, [13] control log
- * density; [14] a landmark proposal from the descent on.  A normal build returns
+ * density; [14] a landmark proposal from the descent on; [15] growth (new state
+ * edge, arrivals).  A normal build returns
  * MCMCGPU_ERR_STATE. */
 int mcmcgpu_debug_phase_cycles(mcmcgpu_handle h, uint64_t out[16], int reset);
 

@@ -197,7 +197,7 @@ __device__ __forceinline__ void write_slice_segments(uint32_t* out, uint32_t nf,
   }
 }
 
-enum Op : int { OP_END = 0, OP_EVAL_STATE = 1, OP_EVAL_FEATURE = 2 };
+enum Op : int { OP_END = 0, OP_EVAL_STATE = 1, OP_EVAL_FEATURE = 2, OP_COMMIT = 3 };
 enum Pending : int { PEND_NONE = 0, PEND_UPDATE = 1, PEND_REPARENT = 2 };
 enum Stage : int { ST_EDGE = 0, ST_ARRIVALS = 1, ST_STEPS = 2, ST_NEXT = 3, ST_END_STEPS = 4, ST_DONE = 5 };
 
@@ -231,6 +231,7 @@ struct Shared {
   // driver state (lane 0 only)
   int stage;
   uint32_t tn, upto, arr, arr_end, steps_left, steps_per_ts, end_left, end_done, end_inflight;
+  uint32_t awaiting;  // an evaluation has been posted and its result not yet taken (piece_step)
   uint32_t Tcur, nf;
   double ll;
   double beta;    // inverse temperature of this chain (1 = the reference's sampler)
@@ -1308,24 +1309,33 @@ MG_DEV void driver_advance(const Dev& d, uint32_t c, Shared& S) {
       return;
     }
     switch (S.stage) {
-      case ST_EDGE:
+      case ST_EDGE: {
         if (S.tn > S.upto) {
           S.stage = ST_END_STEPS;
           break;
         }
+        MG_MARK_BEGIN();
         if (S.tn > 0) driver_add_state_edge(d, c, S);
         S.arr = d.toff[S.tn];
         S.arr_end = d.toff[S.tn + 1];
         S.stage = ST_ARRIVALS;
+        MG_MARK(S, 15);
         break;
-      case ST_ARRIVALS:
+      }
+      case ST_ARRIVALS: {
+        MG_MARK_BEGIN();
         while (S.arr < S.arr_end) {
           const uint32_t o = d.tobs[S.arr++];
-          if (driver_arrival(d, c, S, o)) return;
+          if (driver_arrival(d, c, S, o)) {
+            MG_MARK(S, 15);
+            return;
+          }
         }
         S.steps_left = S.steps_per_ts;
         S.stage = ST_STEPS;
+        MG_MARK(S, 15);
         break;
+      }
       case ST_STEPS:
         while (S.steps_left > 0) {
           --S.steps_left;
@@ -1418,9 +1428,6 @@ MG_DEV void chain_state_store(const Dev& d, uint32_t c, Shared& S) {
 // pointers, so that after inlining inside each piece every access is still a
 // scalar load resp. an LDS operation.
 
-MG_PIECE void piece_driver_advance(DevArgs dp, SharedLds sp, uint32_t c) {
-  driver_advance(*(const Dev*)dp, c, *(Shared*)sp);
-}
 
 // The evaluation is compiled INTO the kernel (one kernel per observation model), the serial pieces
 // around it are calls: a called evaluation saves and restores the callee-saved half of its 128
@@ -1444,23 +1451,44 @@ MG_DEV double inline_eval(DevArgs dp, SharedLds sp, uint32_t c, int op, uint32_t
   return r;
 }
 
-// lane 0 only
-MG_PIECE void piece_finish_update(DevArgs dp, SharedLds sp, uint32_t c, uint32_t idx, double r) {
+// Lane 0's serial program between two requests to the workgroup, as ONE call: the end of the update
+// whose evaluation has just come back (`r`; accept test and bookkeeping), then -- unless an accepted
+// state edge first needs all lanes for the pose table (OP_COMMIT) -- on to the next request.  One
+// call per update instead of two: a call costs a lone lane the save and reload of its registers.
+MG_PIECE void piece_step(DevArgs dp, SharedLds sp, uint32_t c, double r) {
   const Dev& d = *(const Dev*)dp;
   Shared& S = *(Shared*)sp;
-  const bool accept = driver_finish_update(d, c, S, r);
-  S.accept = accept ? 1 : 0;
-  if (S.pending == PEND_UPDATE) {
-    if (accept) ++S.n_acc;
-  } else if (!accept) {  // rejected re-parenting update: reset the edge weight, :321-322
-    const uint32_t o = S.rp_obs;
-    const size_t fi = size_t(c) * d.Fcap + idx;
-    wt::set(landmark_tree(d, c, S), S.nf, idx,
-            edge_weight_from_log_pdf(reading_proposal_log_pdf(load_reading(d, o), Vec2{d.fex[fi], d.fey[fi]}), 2.0,
-                                     nullptr));
-    S.w_dirty = 1;
+  if (S.awaiting) {
+    S.awaiting = 0;
+#ifdef MG_PHASE_TIMING
+    const long long tf0 = clock64();
+#endif
+    const uint32_t idx = S.idx;
+    const bool accept = driver_finish_update(d, c, S, r);
+    S.accept = accept ? 1 : 0;
+    if (S.pending == PEND_UPDATE) {
+      if (accept) ++S.n_acc;
+    } else if (!accept) {  // rejected re-parenting update: reset the edge weight, :321-322
+      const uint32_t o = S.rp_obs;
+      const size_t fi = size_t(c) * d.Fcap + idx;
+      wt::set(landmark_tree(d, c, S), S.nf, idx,
+              edge_weight_from_log_pdf(reading_proposal_log_pdf(load_reading(d, o), Vec2{d.fex[fi], d.fey[fi]}), 2.0,
+                                       nullptr));
+      S.w_dirty = 1;
+    }
+    S.pending = PEND_NONE;
+#ifdef MG_PHASE_TIMING
+    const long long tf1 = clock64();
+    S.phase[4] += tf1 - tf0;  // the accept test's share of this call; the kernel books the whole call to slot 0
+    S.phase[0] -= tf1 - tf0;
+#endif
+    if (S.op == OP_EVAL_STATE && accept) {
+      S.op = OP_COMMIT;
+      return;
+    }
   }
-  S.pending = PEND_NONE;
+  driver_advance(d, c, S);
+  if (S.op == OP_EVAL_STATE || S.op == OP_EVAL_FEATURE) S.awaiting = 1;
 }
 
 MG_PIECE void piece_commit(DevArgs dp, SharedLds sp, uint32_t c, uint32_t idx, double qx, double qy, double qth,
@@ -1512,13 +1540,15 @@ __global__ void advance_kernel(Dev d, uint32_t first_tn, uint32_t Tcur0, uint32_
     S.end_left = end_steps;
     S.end_done = 0;
     S.end_inflight = 0;
+    S.awaiting = 0;
     S.stage = grow ? ST_EDGE : ST_END_STEPS;
   }
   __syncthreads();
   MG_STAMP(tk0);
+  double r = 0.0;
   for (;;) {
     MG_STAMP(td0);
-    if (threadIdx.x == 0) piece_driver_advance(dp, sp, c);
+    if (threadIdx.x == 0) piece_step(dp, sp, c, r);
     __syncthreads();
     MG_STAMP(td1);
     MG_PHASE_ADD(S, 0, td0, td1);
@@ -1527,17 +1557,16 @@ __global__ void advance_kernel(Dev d, uint32_t first_tn, uint32_t Tcur0, uint32_
     const uint32_t idx = S.idx;
     const double qx = S.q[0], qy = S.q[1], qth = S.q[2];
     const uint32_t Tcur = S.Tcur, nf = S.nf;
-    const double r = inline_eval<RB>(dp, sp, c, op, idx, qx, qy, qth, nf);
+    if (op == OP_COMMIT) {  // the state edge just accepted: all lanes move the pose table, then lane 0 goes on
+      piece_commit(dp, sp, c, idx, qx, qy, qth, Tcur);
+      __syncthreads();
+      MG_STAMP(tg1);
+      MG_PHASE_ADD(S, 5, td1, tg1);
+      continue;
+    }
+    r = inline_eval<RB>(dp, sp, c, op, idx, qx, qy, qth, nf);
     MG_STAMP(te1);
     if (op != OP_EVAL_STATE) MG_PHASE_ADD(S, 3, td1, te1);
-    if (threadIdx.x == 0) piece_finish_update(dp, sp, c, idx, r);
-    __syncthreads();
-    MG_STAMP(tf1);
-    MG_PHASE_ADD(S, 4, te1, tf1);
-    if (op == OP_EVAL_STATE && S.accept) piece_commit(dp, sp, c, idx, qx, qy, qth, Tcur);
-    __syncthreads();
-    MG_STAMP(tg1);
-    MG_PHASE_ADD(S, 5, tf1, tg1);
   }
   MG_STAMP(tk1);
   MG_PHASE_ADD(S, 6, tk0, tk1);

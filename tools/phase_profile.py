@@ -32,7 +32,8 @@ def fine(cyc, nprop, nstate):
     print(f"    {'landmark proposal, descent to end':36s} {cyc[14] / max(nprop - nstate, 1):10.0f} cycles per landmark proposal")
     for slot, name in FINE[:2]:
         print(f"    {name:36s} {cyc[slot] / max(nprop, 1):10.0f} cycles per update")
-    inside = float(sum(cyc[k] for k in range(8, 15)))
+    print(f"    {'growth (new edge, arrivals)':36s} {cyc[15] / max(nprop, 1):10.0f} cycles per update")
+    inside = float(sum(cyc[k] for k in range(8, 16)))
     print(f"    {'driver state machine, calls, stores':36s} {(float(cyc[0]) - inside) / max(nprop, 1):10.0f} cycles per update")
 
 
