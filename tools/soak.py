@@ -2,7 +2,9 @@
 """Long run on the benchmark's problem with the invariants checked as it goes: after every launch the
 incremental log likelihood of every chain against the from-scratch one (1e-9 relative), no chain stopped,
 counters consistent.  tools/soak.py [launches=50] [updates per launch=1000] [rebuild every=5] [chains=1024]
-[split slices=0: the persistent kernel; >0: split mode with that many slices]"""
+[split slices=0: the persistent kernel; >0: split mode with that many slices] [problem=bench: the benchmark's;
+commit-heavy: 10 000 poses, 2 nearest landmarks, sigma 3 m -- one proposal in eight is accepted, so the
+pose table, the kept log densities and the landmarks' parent copies are rewritten all the time]"""
 import os
 import sys
 import time
@@ -17,7 +19,11 @@ def main():
     launches = int(sys.argv[1]) if len(sys.argv) > 1 else 50
     per = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     rebuild_every = int(sys.argv[3]) if len(sys.argv) > 3 else 5
-    p = synthetic.make_problem(T=100_000, n_landmarks=1000, k_nearest=10, seed=12345)
+    heavy = len(sys.argv) > 6 and sys.argv[6] == "commit-heavy"
+    if heavy:
+        p = synthetic.make_problem(T=10_000, n_landmarks=1000, k_nearest=2, seed=12345, range_stddev=3.0)
+    else:
+        p = synthetic.make_problem(T=100_000, n_landmarks=1000, k_nearest=10, seed=12345)
     C = int(sys.argv[4]) if len(sys.argv) > 4 else 1024
     slices = int(sys.argv[5]) if len(sys.argv) > 5 else 0
     g = capi.McmcGpu(C, p["T"], p["F"], p["N"], max_split_slices=slices, split_commit_min_poses=1 if slices else 0)
