@@ -444,7 +444,11 @@ struct RatioStream {
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
+#ifdef MG_DIAG_RECORD_WINDOW  // diagnostic builds (tools/window_probe.sh): wrong results, known traffic
+      const StreamRec rec = d.osr[r.o[u] & 4095u];
+#else
       const StreamRec rec = d.osr[r.o[u]];
+#endif
       r.t[u] = rec.t;
       r.mu[u] = rec.mu;
     }
@@ -452,7 +456,11 @@ struct RatioStream {
   MG_DEV void request_poses(uint32_t i0, const Recs& r, Poses& p) {
     if (i0 >= total) return;
 #pragma unroll
+#ifdef MG_DIAG_POSE_WINDOW
+    for (int u = 0; u < U; ++u) p.p[u] = pxy[r.t[u] & 1023u];
+#else
     for (int u = 0; u < U; ++u) p.p[u] = pxy[r.t[u]];
+#endif
   }
   MG_DEV void step(uint32_t i0, Recs& r_this, const Recs& r_next, const Poses& p_this, Poses& p_next) {
     const uint32_t group = U * stride;
@@ -1202,7 +1210,11 @@ MG_DEV bool driver_finish_update(const Dev& d, uint32_t c, Shared& S, double obs
     normaliser += (new_weight - old_weight) / weight_sum;
     accept_log_ratio += new_log_weight - old_log_weight;
   }
+#ifdef MG_DIAG_REJECT_ALL  // diagnostic builds: the chains stay where they are whatever the streams computed
+  const bool accept = (normaliser * rng_uniform(S.rng) < exp(accept_log_ratio)) && false;
+#else
   const bool accept = normaliser * rng_uniform(S.rng) < exp(accept_log_ratio);
+#endif
   if (accept) {
     if (is_state) {
       S.llc += S.new_pll - S.old_pll;
