@@ -1599,7 +1599,7 @@ __global__ void advance_kernel(Dev d, uint32_t first_tn, uint32_t Tcur0, uint32_
 // many workgroups.  One workgroup per chain cannot fill the GPU when there are few chains (a
 // single mcmc_slam instance, a ladder of tempered replicas on a long trajectory); here the stream
 // of one proposal is cut into `slices` equal parts.  Same arithmetic per reading as the persistent
-// kernel; the partial sums are added in slice order.  Updates after growth.
+// kernel; the partial sums of the slices are added in a fixed order.  Updates after growth.
 
 MG_DEV void ctl_to_shared(const Dev& d, uint32_t c, Shared& S, uint32_t Tcur) {
   const ChainCtl& k = d.ctl[c];
@@ -1644,6 +1644,15 @@ __global__ void split_ends_kernel(Dev d_by_value, uint32_t Tcur, uint32_t slices
   __shared__ Shared S;
   const uint32_t c = blockIdx.x;
   chain_state_load(d, c, S);
+  // the slices' partial sums, added by all lanes in a fixed order (lane-strided, then the
+  // wavefront tree, then wavefront after wavefront): up to max_slices loads that one lane would
+  // wait for one after the other
+  double part = 0.0;
+  if (finish && d.ctl[c].op != OP_END) {
+    const uint32_t used = active_slices(d.ctl[c].total, slices);
+    for (uint32_t k = threadIdx.x; k < used; k += blockDim.x) part += d.sp_partial[size_t(c) * d.max_slices + k];
+  }
+  const double slices_sum = block_sum(part, S);
   if (threadIdx.x == 0) {
     S.Tcur = Tcur;
     S.accept = 0;
@@ -1652,9 +1661,7 @@ __global__ void split_ends_kernel(Dev d_by_value, uint32_t Tcur, uint32_t slices
       ctl_to_shared(d, c, S, Tcur);
       S.n_upd = 1;
       if (S.op != OP_END) {
-        double r = 0.0;
-        const uint32_t used = active_slices(d.ctl[c].total, slices);
-        for (uint32_t k = 0; k < used; ++k) r += d.sp_partial[size_t(c) * d.max_slices + k];
+        const double r = slices_sum;
         S.n_units = d.ctl[c].total;
         if (S.op == OP_EVAL_STATE) S.n_state = 1;
         const bool accept = driver_finish_update(d, c, S, r);
