@@ -241,7 +241,7 @@ int mcmcgpu_rebuild(mcmcgpu_handle h);
  * segment totals the scan needs when few chains are cut into many workgroups live in a static
  * device array of the library (122 880 bytes per GPU, held until the process ends) instead of
  * allocated memory; the call allocates and frees nothing and runs on `stream` (NULL = the null
- * stream) of `device`.  Limits: chains <= 4096 (MCMCGPU_ERR_CAPACITY beyond), n < 2^32 - 1,
+ * stream) of `device`.  Limits: chains <= 4096 and n <= 0xFFFF0000 (MCMCGPU_ERR_CAPACITY beyond),
  * rel_stride >= n, cum_stride >= n + 1.  All calls on one GPU share that array: calls that may
  * overlap on one GPU (different streams or threads) race and must be serialised by the caller.
  * Errors are reported through mcmcgpu_last_error(NULL). */

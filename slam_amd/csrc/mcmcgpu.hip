@@ -65,7 +65,7 @@ struct mcmcgpu_ctx {
   double timed_ms[2] = {0.0, 0.0};     // finished launches already folded (see fold_timings), per kind
   uint32_t timed_launches[2] = {0, 0};
   // report records of the last mcmcgpu_run_reported that used the library's own buffer
-  mcmcgpu_chain_summary* reports = nullptr;  // [kMaxOwnReports][max_chains]
+  mcmcgpu_chain_summary* reports = nullptr;  // [kMaxOwnReports + 1][max_chains]; the last row stages mcmcgpu_allgather_summaries
   uint32_t report_intervals = 0;
   // hand-off snapshot: device staging, pinned host landing buffer, completion event
   double* snap_dev = nullptr;
@@ -341,6 +341,7 @@ int lay_out(mcmcgpu_handle h, bool with_slack) {
 // the address is asked for once per device (static_scratch_on) and only that pointer is ever
 // handed to a kernel.  All calls on one GPU share the array: calls that overlap there race.
 constexpr uint32_t kStaticScanChains = 4096;  // most chains one mcmcgpu_scan_poses_static call takes
+constexpr uint32_t kStaticScanMaxPoses = 0xFFFF0000u;  // and most relative poses per chain
 constexpr size_t kStaticScratchBytes = (size_t(kScanTargetGroups) + kStaticScanChains) * sizeof(Pose);  // 122 880
 static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
 
@@ -372,25 +373,29 @@ static_assert(sizeof(Shared) <= kAdvanceStaticLds, "advance_kernel's static LDS 
 // workgroups that share a CU (as many as the chain count and the kernel's 128 registers allow).
 // One chain alone on a CU keeps a Plaza-sized tree whole; 1024 chains of 100 000 poses keep every
 // 64th node of the state tree and the whole landmark tree.
-TreeTops plan_tree_tops(const mcmcgpu_ctx* h, uint32_t state_tree_size) {
+TreeTops plan_tree_tops(const mcmcgpu_ctx* h, uint32_t state_nodes) {
   const uint32_t waves = h->nthreads / 64;
   const uint32_t by_registers = std::max<uint32_t>(1, 16 / waves);  // 4 wavefronts per SIMD at 128 registers
   const uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(by_registers, (h->chains + 255) / 256));
-  const size_t budget = (kLdsPerCu / per_cu - kAdvanceStaticLds - 512) / sizeof(double);  // doubles per workgroup
   TreeTops t{0, 0, 0, 0};
-  const uint32_t F = std::max<uint32_t>(h->d.F, 1);
+  // narrow workgroups and many chains: so many workgroups share a CU that the static block is all each gets
+  if (kLdsPerCu / per_cu < kAdvanceStaticLds + 512 + 3 * sizeof(double)) return t;
+  const size_t budget = (kLdsPerCu / per_cu - kAdvanceStaticLds - 512) / sizeof(double);  // doubles per workgroup
+  // a tree of n nodes has the indices 0 .. n - 1: the copy at stride 2^s holds ((n - 1) >> s) + 1 of them
+  const auto held = [](uint32_t nodes, uint32_t shift) { return nodes ? size_t((nodes - 1) >> shift) + 1 : size_t(0); };
+  const uint32_t F = h->d.F;
   uint32_t fs = 0;
-  while (fs < 12 && size_t(F >> fs) + 1 > budget / 3) ++fs;
-  if (size_t(F >> fs) + 1 <= budget / 3) {
+  while (fs < 12 && held(F, fs) > budget / 3) ++fs;
+  if (held(F, fs) <= budget / 3) {
     t.fw_shift = fs;
-    t.fw_n = (F >> fs) + 1;
+    t.fw_n = uint32_t(held(F, fs));
   }
   const size_t left = budget - t.fw_n;
   uint32_t ss = 0;
-  while (ss < 12 && size_t(state_tree_size >> ss) + 1 > left) ++ss;
-  if (size_t(state_tree_size >> ss) + 1 <= left) {
+  while (ss < 12 && held(state_nodes, ss) > left) ++ss;
+  if (held(state_nodes, ss) <= left) {
     t.sw_shift = ss;
-    t.sw_n = (state_tree_size >> ss) + 1;
+    t.sw_n = uint32_t(held(state_nodes, ss));
   }
   return t;
 }
@@ -482,6 +487,8 @@ int ensure_exchange_buffers(mcmcgpu_handle h, int ranks, uint32_t slots) {
   h->comm_slots = slots;
   int rc = dev_alloc(h, &h->gather_send, size_t(kMaxOwnReports) * slots);
   if (!rc) rc = dev_alloc(h, &h->gather_recv, size_t(ranks) * kMaxOwnReports * slots);
+  if (!rc && hipMemset(h->gather_recv, 0, size_t(ranks) * kMaxOwnReports * slots * sizeof(mcmcgpu_chain_summary)) != hipSuccess)
+    rc = fail(h, MCMCGPU_ERR_HIP, "hipMemset of the gather buffer");
   if (!rc && !h->avg_base) rc = dev_alloc(h, &h->avg_base, packed_capacity(h));
   if (!rc && !h->avg_sum) rc = dev_alloc(h, &h->avg_sum, packed_capacity(h));
   if (!rc && !h->bcast) rc = dev_alloc(h, &h->bcast, packed_capacity(h));
@@ -634,7 +641,7 @@ int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out) {
   if (d.trace_cap) ALLOC(d.trace, C * d.trace_cap);
   ALLOC(h->scan_tot, scan_total_slots(C));
   ALLOC(h->seed_stage, C);
-  ALLOC(h->reports, size_t(kMaxOwnReports) * C);
+  ALLOC(h->reports, size_t(kMaxOwnReports + 1) * C);
   d.max_slices = cfg->max_split_slices;
   if (d.max_slices) {
     ALLOC(d.ctl, C);
@@ -997,8 +1004,8 @@ int mcmcgpu_advance(mcmcgpu_handle h, uint32_t upto, uint32_t steps_per_timestep
   const bool grow = upto + 1 > h->next_timestep;
   if (!grow && end_steps == 0) return 0;
   // LDS copies of the tops of the weight trees: as many nodes as fit beside the workgroups that share a CU
-  const uint32_t tree_size = std::max(upto, edges_grown(h)) + 1;
-  const TreeTops tops = plan_tree_tops(h, tree_size);
+  // state edges the chains have by the end of this launch: tree nodes 0 .. upto - 1
+  const TreeTops tops = plan_tree_tops(h, std::max(upto, edges_grown(h)));
   const size_t dyn_lds = (size_t(tops.sw_n) + tops.fw_n) * sizeof(double);
   auto* const kernel = h->cfg.range_bearing ? advance_kernel<true> : advance_kernel<false>;  // one per observation model
   if (dyn_lds > h->advance_lds_allowed) {
@@ -1247,7 +1254,11 @@ int mcmcgpu_scan_poses_static(int32_t device, void* stream, uint32_t chains, uin
   if (chains > kStaticScanChains)
     return fail(nullptr, MCMCGPU_ERR_CAPACITY, "mcmcgpu_scan_poses_static takes at most " +
                                                    std::to_string(kStaticScanChains) + " chains per call");
-  if (n == 0xFFFFFFFFu || rel_stride < n || cum_stride < n + 1)
+  // the plan rounds segment lengths up to whole tiles in 32-bit arithmetic: keep a tile's worth of headroom
+  if (n > kStaticScanMaxPoses)
+    return fail(nullptr, MCMCGPU_ERR_CAPACITY, "mcmcgpu_scan_poses_static takes at most " +
+                                                   std::to_string(kStaticScanMaxPoses) + " relative poses per chain");
+  if (rel_stride < n || cum_stride < n + 1)
     return fail(nullptr, MCMCGPU_ERR_ARGUMENT, "strides shorter than the trajectory");
   if (reinterpret_cast<uintptr_t>(dev_cum_xy) % 16 != 0)
     return fail(nullptr, MCMCGPU_ERR_ARGUMENT, "dev_cum_xy must be 16-byte aligned");
@@ -1599,7 +1610,12 @@ int mcmcgpu_comm_init(mcmcgpu_handle h, int nranks, int rank, const unsigned cha
   if (int rc = ensure_exchange_buffers(h, nranks, slots_per_rank)) return rc;
   ncclUniqueId u;
   std::memcpy(&u, id, sizeof u);
-  RCCL_TRY(h, rccl().CommInitRank(&h->comm, nranks, u, rank));
+  const ncclResult_t made = rccl().CommInitRank(&h->comm, nranks, u, rank);
+  if (made != ncclSuccess) {  // no communicator: back to the buffers of a handle on its own
+    h->comm = nullptr;
+    ensure_exchange_buffers(h, 1, h->cfg.max_chains);
+    return fail(h, MCMCGPU_ERR_HIP, std::string("ncclCommInitRank: ") + rccl().GetErrorString(made));
+  }
   h->comm_rank = rank;
   return 0;
 }
@@ -1624,7 +1640,14 @@ int mcmcgpu_comm_init_all(mcmcgpu_handle* handles, int n, uint32_t slots_per_ran
   }
   std::vector<ncclComm_t> comms(n, nullptr);
   mcmcgpu_handle h0 = handles[0];
-  RCCL_TRY(h0, rccl().CommInitAll(comms.data(), n, devices.data()));
+  const ncclResult_t made = rccl().CommInitAll(comms.data(), n, devices.data());
+  if (made != ncclSuccess) {  // no communicators: every handle back to the buffers of a handle on its own
+    for (int i = 0; i < n; ++i) {
+      hipSetDevice(handles[i]->cfg.device);
+      ensure_exchange_buffers(handles[i], 1, handles[i]->cfg.max_chains);
+    }
+    return fail(h0, MCMCGPU_ERR_HIP, std::string("ncclCommInitAll: ") + rccl().GetErrorString(made));
+  }
   for (int i = 0; i < n; ++i) {
     handles[i]->comm = comms[i];
     handles[i]->comm_rank = i;
@@ -1658,11 +1681,12 @@ int mcmcgpu_allgather_summaries(mcmcgpu_handle h) {
   if (!h) return MCMCGPU_ERR_ARGUMENT;
   if (h->chains == 0) return fail(h, MCMCGPU_ERR_STATE, "no chains");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
-  // the chains' current summaries go through row 0 of the report buffer
-  hipLaunchKernelGGL(summaries_kernel, dim3((h->chains + 255) / 256), dim3(256), 0, h->stream, h->d, h->reports);
+  // the chains' current summaries go through a row of their own behind the report rows, so the
+  // records of the last reported run stay readable (mcmcgpu_get_reports, mcmcgpu_allgather_reports)
+  mcmcgpu_chain_summary* const staging = h->reports + size_t(kMaxOwnReports) * h->cfg.max_chains;
+  hipLaunchKernelGGL(summaries_kernel, dim3((h->chains + 255) / 256), dim3(256), 0, h->stream, h->d, staging);
   HIP_TRY(h, hipGetLastError());
-  h->report_intervals = 1;
-  return gather_records(h, h->reports, 1);
+  return gather_records(h, staging, 1);
 }
 
 int mcmcgpu_allgather_reports(mcmcgpu_handle h) {

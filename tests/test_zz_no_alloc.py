@@ -29,6 +29,21 @@ def sequential_poses(rel):
     return out
 
 
+_warm = set()
+
+
+def warm_up(dev):
+    """The first call on a device makes the runtime load the library's code object (and with it the static
+    array): that one-time cost is not the call's own, so it is paid before free memory is compared."""
+    if dev.index in _warm:
+        return
+    z = torch.zeros(8, dtype=torch.float64, device=dev)
+    capi.scan_poses_static(1, 1, z.data_ptr(), z.data_ptr(), z.data_ptr(), 1, z[2:].data_ptr(), z.data_ptr(), 2,
+                           device=dev.index, stream=torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize(dev)
+    _warm.add(dev.index)
+
+
 def static_scan(rel_by_chain, pad=0):
     """Runs the entry point on device copies of rel_by_chain [C, n, 3]; returns cum [C, n+1, 3]."""
     C, n, _ = rel_by_chain.shape
@@ -41,13 +56,16 @@ def static_scan(rel_by_chain, pad=0):
         comp.append(torch.from_numpy(a).to(dev))
     cum_xy = torch.full((C, cstride, 2), float("nan"), dtype=torch.float64, device=dev)
     cum_th = torch.full((C, cstride), float("nan"), dtype=torch.float64, device=dev)
+    warm_up(dev)
     torch.cuda.synchronize(dev)
-    before = torch.cuda.memory_allocated(dev)
+    # free bytes of the device as the driver counts them (hipMemGetInfo): a hipMalloc or hipFree inside
+    # the library would show here, which torch's own allocator statistics cannot see
+    before = torch.cuda.mem_get_info(dev)[0]
     capi.scan_poses_static(C, n, comp[0].data_ptr(), comp[1].data_ptr(), comp[2].data_ptr(), rstride,
                            cum_xy.data_ptr(), cum_th.data_ptr(), cstride, device=0,
                            stream=torch.cuda.current_stream(dev).cuda_stream)
     torch.cuda.synchronize(dev)
-    assert torch.cuda.memory_allocated(dev) == before
+    assert torch.cuda.mem_get_info(dev)[0] == before, "the call changed the device's free memory"
     out = np.empty((C, n + 1, 3))
     out[:, :, :2] = cum_xy[:, :n + 1].cpu().numpy()
     out[:, :, 2] = cum_th[:, :n + 1].cpu().numpy()
@@ -108,3 +126,5 @@ def test_static_scan_rejects_what_it_cannot_hold():
         capi.scan_poses_static(1, 10, p, p, p, 9, p, p, 11)
     with pytest.raises(RuntimeError, match="null"):
         capi.scan_poses_static(1, 10, 0, p, p, 10, p, p, 11)
+    with pytest.raises(RuntimeError, match="relative poses per chain"):
+        capi.scan_poses_static(1, 0xFFFF0001, p, p, p, 0xFFFF0001, p, p, 0xFFFF0002)
