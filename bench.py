@@ -42,13 +42,17 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=["chains", "tempering", "range-bearing", "commit-heavy"], default="chains",
+    ap.add_argument("--workload", choices=["chains", "tempering", "range-bearing", "commit-heavy", "burn-in"], default="chains",
                     help="chains: the headline workload; tempering: one ladder of "
                          "tempered replicas per GPU on a 1M-pose trajectory with a replica exchange after every launch; "
                          "range-bearing: the headline workload with the reference's other observation model (48 B per unit); "
                          "commit-heavy: 10 000 poses with few, noisy readings per pose (2 nearest landmarks, sigma 3 m), "
                          "the regime of the Plaza logs: an eighth of the proposals is accepted and every accepted state "
-                         "edge re-positions all later poses, a quarter of the algorithmic bytes")
+                         "edge re-positions all later poses, a quarter of the algorithmic bytes; "
+                         "burn-in: the headline problem with every chain heated to --beta (readings' part of the accept "
+                         "test weighed by it, src/slam/mcmc_slam.hpp:408 otherwise), so that a large share of the "
+                         "100 000-pose proposals is accepted: what the commit path costs where it can hurt")
+    ap.add_argument("--beta", type=float, default=1e-3, help="burn-in: inverse temperature of every chain")
     ap.add_argument("--range-stddev", type=float, default=None, help="sigma of the range readings, m (1; commit-heavy: 3)")
     ap.add_argument("--bearing-stddev", type=float, default=0.05, help="range-bearing: sigma of the bearings, rad")
     ap.add_argument("--chains", type=int, default=None, help="chains per GPU (1024; tempering: 64)")
@@ -75,6 +79,15 @@ def parse_args():
     ap.add_argument("--collectives-with-one-rank", action="store_true",
                     help="testing aid: with one rank, still set up an RCCL process group of that one rank and "
                          "run every exchange through it")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not run the two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE) over a short child run of "
+                         "this workload; roofline.traffic then comes from profiles/hbm_traffic*.json when that was taken on "
+                         "the same library, else it is null")
+    ap.add_argument("--live-traffic-seconds", type=float, default=150.0,
+                    help="time allowed for the two counter passes together; a pass that would not fit is not started")
+    ap.add_argument("--dump-records", default=None,
+                    help="rank 0 writes what the job as a whole produced (per-interval chain records of every timed step, "
+                         "best chain, the winner's broadcast state) to this .npz file")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="testing aid: all ranks share GPU 0 and exchange over gloo (RCCL refuses two ranks on one "
                          "device); exercises the N > 1 code path on a one-GPU box, its numbers mean nothing")
@@ -85,7 +98,7 @@ def parse_args():
         args.k_nearest = 2 if heavy else 10
     if args.range_stddev is None:
         args.range_stddev = 3.0 if heavy else 1.0
-    if heavy:
+    if heavy or args.workload == "burn-in":
         args.no_cpu_baseline = args.no_plaza = True
     if args.chains is None:
         args.chains = 64 if tempering else 1024
@@ -146,7 +159,12 @@ def cpu_baseline(problem, seed, target_seconds, all_seeds=None):
     }
     # the same oracle with one chain per host thread (chains are independent): what the box's cores
     # give when the reference's serial multi_mcmc loop (multi_mcmc.hpp:109-118) is simply parallelised
-    cores = max(1, min(16, os.cpu_count() or 1))  # a one-GPU box's share of the host is 16 cores
+    # every core this process may run on (the scheduler's affinity mask, which is what a container's share of
+    # the host shows as): not capped
+    try:
+        cores = max(1, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        cores = max(1, os.cpu_count() or 1)
     if cores > 1 and all_seeds is not None:
         chains = [c] + [w.add_detached_chain(int(s)) for s in all_seeds[1:cores]]
         for k in chains[1:]:
@@ -158,9 +176,137 @@ def cpu_baseline(problem, seed, target_seconds, all_seeds=None):
         out["all_cores"] = {
             "value": many / dt_all,
             "cores": cores,
-            "sample": f"{len(chains)} chains x {per_chain} updates on {cores} threads ({many} units, {dt_all:.1f} s)",
+            "host_logical_cpus": os.cpu_count(),
+            "sample": f"{len(chains)} chains x {per_chain} updates on {cores} threads = every core this process may use "
+                      f"({many} units, {dt_all:.1f} s)",
         }
     return out
+
+
+def child_argv(args):
+    """The command line of a short run of the same workload (the counter passes below profile it)."""
+    argv = [os.path.abspath(__file__), "--workload", args.workload, "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+            "--no-plaza", "--no-live-traffic", "--chains", str(args.chains), "--updates-per-step", str(args.updates_per_step),
+            "--report-every", str(args.report_every), "--timesteps", str(args.timesteps), "--landmarks", str(args.landmarks),
+            "--k-nearest", str(args.k_nearest), "--seed", str(args.seed), "--rebuild-every", str(args.rebuild_every),
+            "--threads-per-chain", str(args.threads_per_chain), "--split-slices", str(args.split_slices),
+            "--range-stddev", repr(args.range_stddev), "--bearing-stddev", repr(args.bearing_stddev),
+            "--beta-min", repr(args.beta_min), "--beta", repr(args.beta)]
+    return argv, 3  # launches (steps + warm-up) of that run
+
+
+def live_traffic(args, split_mode, budget_s=150.0):
+    """HBM-side bytes per launch of the dominant kernel, measured now: two rocprofv3 --pmc passes (FETCH_SIZE,
+    WRITE_SIZE; one counter each, they do not fit one pass) over a short child run of this very workload on the
+    library this process runs.  FETCH_SIZE and WRITE_SIZE are reported in KiB; gfx950 tallies a 128-byte read
+    request at 64 bytes, and every read this kernel sends out of L2 is a 128-byte one, so reads count double.
+    Requests leaving L2 are counted, Infinity-Cache hits included.  Returns (bytes per launch or None, record)."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    rec = {"method": "rocprofv3 --pmc, one pass per counter, over a child run of this workload (2 timed + 1 warm-up launches)"}
+    if not os.path.exists(prof):
+        rec["failed"] = "rocprofv3 not found"
+        return None, rec
+    argv, launches = child_argv(args)
+    names = ("split_",) if split_mode else ("advance_kernel",)
+    got = {}
+    t_begin = time.perf_counter()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+        cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable] + argv
+        env = dict(os.environ, TMPDIR="/tmp")
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        try:
+            left = budget_s - (time.perf_counter() - t_begin)
+            if left < 20:
+                raise TimeoutError("time budget of the counter passes used up")
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                    start_new_session=True)
+            try:
+                proc.wait(timeout=left)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)  # the process group this call started, nothing else
+                proc.wait()
+                raise TimeoutError(f"{counter} pass did not finish in {left:.0f} s")
+            if proc.returncode != 0:
+                raise RuntimeError(f"{counter} pass ended with code {proc.returncode}")
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                raise RuntimeError(f"{counter} pass left no counter_collection.csv")
+            total, rows = 0.0, 0
+            with open(files[0]) as f:
+                for r in csv.DictReader(f):
+                    if r["Counter_Name"] == counter and any(n in r["Kernel_Name"] for n in names):
+                        total += float(r["Counter_Value"])
+                        rows += 1
+            if rows == 0:
+                raise RuntimeError(f"{counter} pass saw none of the kernels {names}")
+            got[counter] = total * 1024.0 / launches
+            rec[counter.lower() + "_reported_bytes_per_launch"] = got[counter]
+            rec[counter.lower() + "_dispatches"] = rows
+        except Exception as e:  # noqa: BLE001 -- the bench line must come out whatever the profiler does
+            rec["failed"] = f"{type(e).__name__}: {e}"
+            return None, rec
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    rec["seconds"] = time.perf_counter() - t_begin
+    rec["counters"] = "2 x FETCH_SIZE + WRITE_SIZE: requests leaving L2, Infinity-Cache hits included"
+    return 2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"], rec
+
+
+def quoted_traffic(args, workload_name):
+    """roofline.traffic from the last committed profiling round (profiles/hbm_traffic*.json), only when that was
+    taken on the library that is running now."""
+    import glob
+
+    running_sha = library_sha16()
+    traffic, source = None, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "hbm_traffic*.json"))):
+        try:
+            with open(path) as f:
+                rec = json.load(f)
+            if rec["updates_per_step"] != args.updates_per_step or rec["workload"] != workload_name:
+                continue
+            source = {"method": "quoted from " + os.path.relpath(path, ROOT), "date": rec.get("date"),
+                      "commit": rec.get("commit"), "library_sha16": rec.get("library_sha16"),
+                      "running_library_sha16": running_sha,
+                      "counters": "2 x FETCH_SIZE + WRITE_SIZE: requests leaving L2, Infinity-Cache hits included"}
+            if rec.get("library_sha16") == running_sha:
+                traffic = rec["traffic_bytes_per_launch"]
+            else:
+                source["withheld"] = "the profile was taken on another build of the library"
+        except (OSError, ValueError, KeyError):
+            pass
+    return traffic, source
+
+
+def hbm_only_bracket(workload_name, updates_per_step, units_per_launch, traffic):
+    """Which part of `traffic` (requests leaving L2) goes on to HBM and which the 256 MB Infinity Cache serves
+    cannot be counted on this GPU (rocprofv3 lists no counter beyond the L2's memory-side interface), so it is
+    bracketed from the window probe (tools/window_probe.sh -> profiles/window_probe.json): the reading records
+    (12 MB, shared by all chains, re-read by every proposal) stay in the Infinity Cache, the pose tables
+    (1.6 MB per chain, 1.6 GB in all) do not fit.  low = pose lines only; high = everything but the records."""
+    path = os.path.join(ROOT, "profiles", "window_probe.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        if rec["workload"] != workload_name or rec["updates_per_step"] != updates_per_step:
+            return None
+        pose, records = rec["pose_line_bytes_per_unit"], rec["record_bytes_per_unit"]
+        low = pose * units_per_launch
+        high = traffic - records * units_per_launch
+        return {"low_bytes_per_launch": low, "high_bytes_per_launch": high, "source": os.path.relpath(path, ROOT),
+                "library_sha16": rec.get("library_sha16"), "running_library_sha16": library_sha16(),
+                "basis": "bracket: pose-table lines only .. all requests but the reading records' (which the Infinity Cache holds)"}
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def plaza_wall(name, device, with_cpu):
@@ -272,6 +418,7 @@ def main():
 
     tempering = args.workload == "tempering"
     bearing = args.workload == "range-bearing"
+    burn_in = args.workload == "burn-in"
     problem = synthetic.make_problem(T=args.timesteps, n_landmarks=args.landmarks, k_nearest=args.k_nearest,
                                      seed=args.seed, max_tries=2 if tempering else 8, range_stddev=args.range_stddev,
                                      bearing_stddev=args.bearing_stddev if bearing else None)
@@ -297,6 +444,8 @@ def main():
     g.load_state(problem["true_rel"], problem["landmarks"])
     if tempering:  # one ladder per GPU: slot 0 is the untempered chain
         g.set_ladders(np.geomspace(1.0, args.beta_min, C), exchange_seed=args.seed + 3 + rank)
+    if burn_in:  # every chain a "ladder" of its own at one inverse temperature; nothing is ever exchanged
+        g.set_ladders(np.array([args.beta]), exchange_seed=args.seed + 3 + rank)
     g.sync()
 
     intervals = -(-args.updates_per_step // args.report_every)
@@ -304,7 +453,10 @@ def main():
     summaries = torch.zeros((intervals, C, 2), dtype=torch.float64, device=dev)
     best = {"ll": float("-inf"), "chain": -1}
 
-    def one_step(i):
+    gather_events = []  # (before, after) the exchange of every timed step, on the stream everything runs on
+    dumped = []         # --dump-records: the gathered records of every timed step
+
+    def one_step(i, timed=False):
         if args.split_slices:
             g.run_split_reported(args.updates_per_step, args.split_slices, args.report_every, summaries.data_ptr())
         else:
@@ -313,7 +465,15 @@ def main():
             g.rebuild()
         if tempering:
             g.exchange(i % 2)
+        if timed:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         gathered = parallel.gather_summaries(summaries, world)  # RCCL all-gather when world > 1
+        if timed:
+            ev[1].record()
+            gather_events.append(ev)
+            if args.dump_records and rank == 0:
+                dumped.append(gathered.cpu().numpy().copy())
         # best log likelihood of every report interval, stays on the device
         return gathered[-1], torch.max(gathered[:, :, 0], dim=1).values
 
@@ -338,7 +498,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        gathered, ll = one_step(args.warmup + i)
+        gathered, ll = one_step(args.warmup + i, timed=True)
     barrier()
     elapsed = time.perf_counter() - t0
     note("timed steps done")
@@ -365,35 +525,36 @@ def main():
     parallel.all_reduce(tot, dist.ReduceOp.SUM, world)
     elapsed_max = float(t.item())
     units_total, updates_total, accepts_total = (float(x) for x in tot.tolist())
+    # what every rank saw, gathered through the same collective the steps use: the record of an N-GPU run then
+    # shows by itself that the backend had N ranks and where any loss against N x one GPU is (kernel tail or exchange)
+    gather_ms = [a.elapsed_time(b) for a, b in gather_events]
+    props = torch.cuda.get_device_properties(dev)
+    mine = torch.tensor([[rank, local_rank, kern_ms, launches, 1e3 * elapsed / max(args.steps, 1),
+                          sum(gather_ms) / max(len(gather_ms), 1), max(gather_ms, default=0.0), d_units,
+                          float(getattr(props, "pci_bus_id", -1)), float(getattr(props, "pci_device_id", -1))]],
+                        dtype=torch.float64, device=dev)
+    per_rank = parallel.gather_summaries(mine, world).cpu().numpy()
 
     workload_name = ("synthetic planar robot: %d poses, %d landmarks, %d range readings, %d %s per GPU" %
                      (T, F, N, C, "tempered replicas (one ladder)" if tempering else
                       "chains, range-and-bearing readings" if bearing else
                       "chains, commit-heavy (%d nearest, sigma %g m)" % (args.k_nearest, args.range_stddev)
-                      if args.workload == "commit-heavy" else "chains"))
+                      if args.workload == "commit-heavy" else
+                      "chains heated to beta %g (burn-in)" % args.beta if burn_in else "chains"))
     if rank == 0:
-        # HBM-side bytes per launch cannot be read from inside this process (they come from rocprofv3 --pmc
-        # passes over this very command, tools/profile_round.sh): the record of the last profiling round is
-        # quoted, and only if it was taken on the library that is running now
+        # HBM-side bytes per launch: measured now by counter passes over a short child run (one GPU only), else
+        # quoted from the last committed profiling round when that was taken on this library, else null
         traffic, traffic_source = None, None
-        running_sha = library_sha16()
-        import glob
-        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "hbm_traffic*.json"))):
-            try:
-                with open(path) as f:
-                    rec = json.load(f)
-                if rec["updates_per_step"] != args.updates_per_step or rec["workload"] != workload_name:
-                    continue
-                traffic_source = {"file": os.path.relpath(path, ROOT), "date": rec.get("date"), "commit": rec.get("commit"),
-                                  "library_sha16": rec.get("library_sha16"), "running_library_sha16": running_sha,
-                                  "counters": "2 x FETCH_SIZE + WRITE_SIZE (gfx950 tallies a wide read at half its bytes); "
-                                              "requests leaving L2, Infinity-Cache hits included"}
-                if rec.get("library_sha16") == running_sha:
-                    traffic = rec["traffic_bytes_per_launch"]
-                else:
-                    traffic_source["withheld"] = "the profile was taken on another build of the library"
-            except (OSError, ValueError, KeyError):
-                pass
+        if world == 1 and not args.no_live_traffic:
+            g.sync()
+            traffic, traffic_source = live_traffic(args, bool(args.split_slices), args.live_traffic_seconds)
+        if traffic is None:
+            failed = traffic_source
+            traffic, traffic_source = quoted_traffic(args, workload_name)
+            if failed is not None and traffic_source is not None:
+                traffic_source["live_pass"] = failed
+            elif failed is not None:
+                traffic_source = failed
         # a range-and-bearing reading also needs the pose's angle and the measured bearing: 48 bytes
         unit_bytes = BYTES_PER_UNIT + 16 if bearing else BYTES_PER_UNIT
         commit_bytes = d_moved * BYTES_PER_MOVED_POSE / max(launches, 1)
@@ -413,6 +574,51 @@ def main():
                 "bytes_per_launch": scan_bytes, "achieved": scan_bytes / (rebuild_ms * 1e-3) / 1e9 if rebuild_ms > 0 else 0.0,
                 "frac": scan_bytes / (rebuild_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if rebuild_ms > 0 else 0.0,
             })
+        kern_s = kern_ms * 1e-3
+        counter_gbs = traffic / kern_s / 1e9 if traffic and kern_s > 0 else None
+        roofline = {
+            "bound": "hbm",
+            # frac: bytes the counters saw leave L2 per launch (HBM + Infinity Cache) over the kernel's device time
+            # and the HBM peak -- a physical fraction, at most 1.  algorithmic_frac: the per-unit byte figure of the
+            # metric's definition (32 B per proposal*observation, 48 B with bearings, + per-proposal landmark table
+            # + 48 B per re-positioned pose) over the same time; it exceeds 1 where caches serve shared records
+            # and neighbouring pose lines, and says how much work is done per second, not how busy HBM is.
+            "achieved": counter_gbs,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": counter_gbs / HBM_PEAK_GBS if counter_gbs is not None else None,
+            "traffic": traffic,
+            "traffic_source": traffic_source,
+            "basis": "achieved = roofline.traffic (2 x FETCH_SIZE + WRITE_SIZE of the dominant kernel per launch: requests "
+                     "that leave L2, Infinity-Cache hits included) / kernel_ms; null when no counter pass is available",
+            "algorithmic_bytes_per_launch": bytes_per_launch,
+            "algorithmic_achieved": achieved,
+            "algorithmic_frac": achieved / HBM_PEAK_GBS,
+            "traffic_over_algorithmic": traffic / bytes_per_launch if traffic and bytes_per_launch else None,
+            "kernel": "split_* kernel sequence of one step" if args.split_slices else "advance_kernel",
+            "kernel_ms": kern_ms,
+            "launches": launches,
+            "other_kernels": other_kernels,
+        }
+        if traffic:
+            only = hbm_only_bracket(workload_name, args.updates_per_step, d_units / max(launches, 1), traffic)
+            if only:
+                only["low_frac"] = only["low_bytes_per_launch"] / kern_s / 1e9 / HBM_PEAK_GBS
+                only["high_frac"] = only["high_bytes_per_launch"] / kern_s / 1e9 / HBM_PEAK_GBS
+                roofline["hbm_only"] = only
+        collective = {
+            "backend": dist.get_backend() if dist.is_initialized() else "none (one rank, no process group)",
+            "world_size": dist.get_world_size() if dist.is_initialized() else 1,
+            "exchange": "all-gather of %d report rows x %d chains x 16 B per rank every step = %d B gathered" %
+                        (intervals, C, intervals * C * 16 * world),
+            "allgather_ms_per_step": {"mean_over_ranks_max": float(per_rank[:, 5].max()), "worst_step": float(per_rank[:, 6].max())},
+            "kernel_ms_per_rank": {"min": float(per_rank[:, 2].min()), "max": float(per_rank[:, 2].max()),
+                                   "all": [float(x) for x in per_rank[:, 2]]},
+            "step_ms_per_rank": {"min": float(per_rank[:, 4].min()), "max": float(per_rank[:, 4].max())},
+            "units_per_rank": [float(x) for x in per_rank[:, 7]],
+            "ranks": [{"rank": int(r[0]), "local_rank": int(r[1]), "pci_bus_id": int(r[8]), "pci_device_id": int(r[9])}
+                      for r in per_rank],
+        }
         out = {
             "metric": "MCMC proposals*observations/sec (node) on 100k-pose synthetic",
             "value": units_total / elapsed_max,
@@ -436,27 +642,10 @@ def main():
                 "start_state": "generating trajectory and landmark positions (mcmcgpu_load_state)",
                 "range_stddev": args.range_stddev,
                 "k_nearest": args.k_nearest,
+                **({"beta": args.beta} if burn_in else {}),
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "basis": "ALGORITHMIC bytes (32 B per proposal*observation + per-proposal landmark table + 48 B per "
-                         "re-positioned pose) over the kernel's device time: the 16-byte reading records are shared by "
-                         "all chains and largely served from L2 / Infinity Cache, so this fraction can exceed what "
-                         "HBM itself delivers -- hbm_frac is the counter-based figure",
-                "traffic": traffic,
-                "hbm_frac": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and kern_ms > 0 else None,
-                "cache_served_bytes_per_launch": (bytes_per_launch - traffic) if traffic else None,
-                "traffic_source": traffic_source,
-                "other_kernels": other_kernels,
-                "kernel": "split_* kernel sequence of one step" if args.split_slices else "advance_kernel",
-                "kernel_ms": kern_ms,
-                "launches": launches,
-                "algorithmic_bytes_per_launch": bytes_per_launch,
-            },
+            "roofline": roofline,
+            "collective": collective,
             "proposals_per_s": updates_total / elapsed_max,
             "accept_rate": accepts_total / max(updates_total, 1.0),
             "units_per_proposal": units_total / max(updates_total, 1.0),
@@ -468,6 +657,9 @@ def main():
             out["config"]["beta"] = "geometric 1 .. %g over %d slots, exchange after every launch" % (args.beta_min, C)
             out["config"]["threads_per_chain"] = args.threads_per_chain
             out["exchange"] = {"attempts": attempts, "swaps": swaps, "chain_at_beta_1": int(slot[0])}
+        if args.dump_records:
+            np.savez(args.dump_records, records=np.stack(dumped), best=np.array([best["ll"], best["chain"]]),
+                     winner=packed.cpu().numpy())
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(problem, all_seeds[0], args.cpu_seconds, all_seeds)
         if world == 1 and not args.no_plaza:

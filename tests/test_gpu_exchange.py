@@ -37,6 +37,8 @@ def test_collectives_of_one_rank_equal_the_local_entry_points(with_comm):
     assert now.shape == (1, 1, 8)
     assert np.array_equal(now[0, 0, :5]["log_likelihood"], g.log_likelihood())
     assert np.all(now[0, 0, :5]["updates"] == 250)
+    # the current summaries went through a row of their own: the reported run's records are still there
+    assert np.array_equal(g.get_reports(), local)
     # the best chain's state, broadcast from its owner (here: to itself)
     best = int(np.argmax(g.log_likelihood()))
     g.broadcast_state(0, best)

@@ -86,3 +86,49 @@ def test_bench_exchanges_through_rccl_and_prints_one_line():
     assert len(lines) == 1, out.stdout
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 1 and rec["config"]["chains_total"] == 8 and rec["value"] > 0
+
+
+def _bench_job(tmp_path, tag, gpus, *extra):
+    import json
+
+    dump = tmp_path / (tag + ".npz")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--total-chains", "8192",
+                          "--updates-per-step", "1000", "--report-every", "100", "--steps", "1", "--warmup", "0",
+                          "--rebuild-every", "0", "--no-cpu-baseline", "--no-plaza", "--no-live-traffic",
+                          "--dump-records", str(dump), *extra], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    rec = json.loads([x for x in out.stdout.splitlines() if x.startswith("{")][-1])
+    return rec, np.load(dump)
+
+
+@pytest.mark.gpu
+def test_sharded_configuration_at_its_own_shape(tmp_path):
+    """The baseline's sharded configuration at its real size: 100 000 poses, 1 000 landmarks, 10^6 readings, 8192
+    chains as 8 shards of 1024 (eight ranks that share GPU 0 and exchange over gloo; 53 GB of chain state) against
+    ONE rank with all 8192 chains.  One launch of 1000 updates leaves 10 report rows, so the exchange is the
+    [10 x 8192] gather of multi_mcmc's report loop (src/slam/multi_mcmc.hpp:121-139).  Global chain i is seeded with
+    the i-th draw of one generator (:160-166) and stepped independently (:105-119): every record of every interval,
+    the best chain (first maximum in global chain order, strict `>` at :115) and its broadcast state must be
+    identical bit for bit whatever the rank count."""
+    rec8, eight = _bench_job(tmp_path, "eight", 8, "--rehearse-on-one-gpu")
+    rec1, one = _bench_job(tmp_path, "one", 1)
+    assert rec8["n_gpus"] == 8 and rec8["config"]["chains_total"] == 8192 and rec8["scaling"] == "strong"
+    assert rec8["collective"]["world_size"] == 8 and rec8["collective"]["backend"] == "gloo"
+    assert len(rec8["collective"]["kernel_ms_per_rank"]["all"]) == 8
+    assert rec1["collective"]["world_size"] == 1
+    a = eight["records"].view(capi_summary()).reshape(eight["records"].shape[:-1])
+    b = one["records"].view(capi_summary()).reshape(one["records"].shape[:-1])
+    assert a.shape == b.shape == (1, 10, 8192)
+    assert np.array_equal(a["log_likelihood"], b["log_likelihood"])
+    assert np.array_equal(a["updates"], b["updates"]) and np.array_equal(a["accepts"], b["accepts"])
+    assert np.all(a["updates"][0, -1] == 1000) and np.all(a["updates"][0, 0] == 100)
+    assert np.array_equal(eight["best"], one["best"])
+    assert np.array_equal(eight["winner"], one["winner"]) and np.any(one["winner"] != 0)
+    assert rec8["best_chain"] == rec1["best_chain"] and rec8["best_log_likelihood"] == rec1["best_log_likelihood"]
+
+
+def capi_summary():
+    sys.path.insert(0, ROOT)
+    from slam_amd import capi
+
+    return capi.CHAIN_SUMMARY

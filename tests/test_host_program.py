@@ -315,3 +315,28 @@ def test_multi_mcmc_sharded_over_handles_gives_the_same_run(tmp_path):
         # the average adds the per-handle partial sums in another order
         a, b = float(sharded[1][2].split()[-1]), float(one[1][2].split()[-1])
         assert abs(a - b) <= 1e-9 * abs(b)
+
+
+@pytest.mark.gpu
+def test_multi_mcmc_with_8192_chains_on_eight_handles_gives_the_same_run(tmp_path):
+    """The sharded configuration's chain count through the C++ host: 8192 chains as 8 handles of 1024 (all on
+    GPU 0, exchange through host memory) against one handle of 8192 -- same report lines, same best chain and
+    estimate (src/slam/multi_mcmc.hpp:105-139, 160-166); the average differs by the order of the partial sums."""
+    def job(tag, *extra):
+        d = tmp_path / tag
+        d.mkdir()
+        out = subprocess.run([EXE, "--dataset", "Plaza2", "--dataset-dir", PLAZA, "--multi-mcmc", "--multi-mcmc-chains",
+                              "8192", "--multi-mcmc-end-steps", "200", "--sensor-range-stddev", "4", "--seed", "7", *extra],
+                             capture_output=True, text=True, timeout=900, cwd=d)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        keep = [ln for ln in out.stdout.splitlines() if ln.startswith(("Multi-MCMC-SLAM log", "Multi-MCMC-SLAM best", "Averaged"))]
+        return open(d / "multi-mcmc-report.txt").read(), keep, out.stdout
+
+    one = job("one")
+    eight = job("eight", "--devices", "0,0,0,0,0,0,0,0", "--exchange", "host")
+    assert "8192 on 8 handle(s), exchange through host memory" in eight[2]
+    assert len(one[0].splitlines()) == 2
+    assert eight[0] == one[0]
+    assert eight[1][:2] == one[1][:2]
+    a, b = float(eight[1][2].split()[-1]), float(one[1][2].split()[-1])
+    assert abs(a - b) <= 1e-9 * abs(b)

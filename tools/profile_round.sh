@@ -11,7 +11,7 @@ EXTRA="$*"
 R=$(pwd)
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
-BENCH_ARGS="--steps 6 --warmup 2 --no-cpu-baseline --no-plaza $EXTRA"
+BENCH_ARGS="--steps 6 --warmup 2 --no-cpu-baseline --no-plaza --no-live-traffic $EXTRA"
 cd /tmp
 export TMPDIR=/tmp
 timeout -k 10 300 python3 "$R/bench.py" --steps 10 --warmup 2 $EXTRA > "$OUT/bench.json" 2> "$OUT/bench.err"

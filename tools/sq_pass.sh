@@ -9,7 +9,7 @@ mkdir -p "$OUT"
 cd /tmp
 export TMPDIR=/tmp
 timeout -s KILL 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$OUT/sq" -- \
-  python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-plaza > "$OUT/sq.log" 2>&1
+  python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-plaza --no-live-traffic > "$OUT/sq.log" 2>&1
 cd "$R"
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections

@@ -39,8 +39,13 @@ def main():
         print("== bench ==")
         print(f"value {bench['value']:.4g} {bench['unit']}  ms/step {bench['ms_per_step']:.2f}  "
               f"updates/step {bench['config']['updates_per_step']}")
-        print(f"roofline: achieved {r['achieved']:.1f} GB/s of {r['peak']:.0f} = {r['frac']:.3f}  "
+        if r.get("frac") is not None:
+            print(f"roofline (counters, bytes leaving L2): {r['achieved']:.1f} GB/s of {r['peak']:.0f} = {r['frac']:.3f}  "
+                  f"traffic/launch {r['traffic']:.4g} B  ({(r.get('traffic_source') or {}).get('method')})")
+        print(f"algorithmic: {r['algorithmic_achieved']:.1f} GB/s = {r['algorithmic_frac']:.3f} of peak  "
               f"kernel {r['kernel_ms']:.3f} ms x {r['launches']}  algorithmic bytes/launch {r['algorithmic_bytes_per_launch']:.4g}")
+        if r.get("hbm_only"):
+            print(f"HBM only (bracket): {r['hbm_only']['low_frac']:.3f} .. {r['hbm_only']['high_frac']:.3f} of peak")
         if "cpu_baseline" in bench:
             c = bench["cpu_baseline"]
             print(f"cpu_baseline: {c['value']:.4g} {c['unit']} on {c['cores']} core ({c['sample']})")

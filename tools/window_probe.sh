@@ -22,7 +22,7 @@ O=$R/gpurun_out/window_probe
 mkdir -p "$O"
 cd /tmp
 export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-plaza"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-plaza --no-live-traffic"
 for v in NONE POSE RECORD; do
   export MCMCGPU_LIB=$R/tools/diag/libmcmcgpu_win_$v.so
   timeout -k 10 120 python3 "$R/bench.py" $ARGS > "$O/bench_$v.json" 2> "$O/bench_$v.err"
@@ -31,10 +31,14 @@ for v in NONE POSE RECORD; do
 done
 cd "$R"
 python3 - <<'PY' | tee gpurun_out/window_probe/summary.txt
-import csv, glob, json, os
+import csv, datetime, glob, json, os, sys
+sys.path.insert(0, os.getcwd())
+import bench as bench_module
 names = {"NONE": "as it is", "POSE": "pose gathers in a 16 KB window", "RECORD": "record loads in a 48 KB window"}
+per_unit, rate, cfg = {}, {}, None
 for v in ("NONE", "POSE", "RECORD"):
-    b = json.load(open(f"gpurun_out/window_probe/bench_{v}.json"))
+    b = json.loads([ln for ln in open(f"gpurun_out/window_probe/bench_{v}.json") if ln.startswith("{")][-1])
+    cfg = b["config"]
     units = b["value"] * b["ms_per_step"] / 1e3
     f = max(glob.glob(f"gpurun_out/window_probe/fetch_{v}/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
     tot = n = 0
@@ -43,6 +47,14 @@ for v in ("NONE", "POSE", "RECORD"):
             tot += float(r["Counter_Value"])
             n += 1
     reads = 2 * tot / max(n, 1) * 1024  # KiB as reported, 128-byte requests tallied at 64
+    per_unit[v], rate[v] = reads / units, b["value"]
     print(f"{names[v]:34s} {b['value']:.4g} units/s, kernel {b['roofline']['kernel_ms']:.1f} ms, "
           f"reads leaving L2 {reads:.4g} B per launch = {reads / units:.1f} B per unit")
+# what bench.py brackets HBM-only traffic with: pose lines = what confining the pose gathers removes, records =
+# what is left once the record loads (and with them the pose gathers) are confined
+rec = {"workload": cfg["workload"], "updates_per_step": cfg["updates_per_step"], "library_sha16": bench_module.library_sha16(),
+       "date": datetime.date.today().isoformat(), "reads_bytes_per_unit": per_unit, "units_per_s": rate,
+       "pose_line_bytes_per_unit": per_unit["NONE"] - per_unit["POSE"], "record_bytes_per_unit": per_unit["RECORD"]}
+json.dump(rec, open("gpurun_out/window_probe/window_probe.json", "w"), indent=1)
+print(f"pose-table lines {rec['pose_line_bytes_per_unit']:.1f} B per unit, reading records {rec['record_bytes_per_unit']:.1f} B per unit")
 PY
