@@ -85,6 +85,9 @@ def parse_args():
                          "the same library, else it is null")
     ap.add_argument("--live-traffic-seconds", type=float, default=150.0,
                     help="time allowed for the two counter passes together; a pass that would not fit is not started")
+    ap.add_argument("--keep-counter-csv", default=None,
+                    help="prefix for copies of the counter passes' rows (the dominant kernel's dispatches only): "
+                         "<prefix>_pmc_fetch_size.csv and <prefix>_pmc_write_size.csv, what roofline.traffic was summed from")
     ap.add_argument("--dump-records", default=None,
                     help="rank 0 writes what the job as a whole produced (per-interval chain records of every timed step, "
                          "best chain, the winner's broadcast state) to this .npz file")
@@ -240,12 +243,19 @@ def live_traffic(args, split_mode, budget_s=150.0):
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             if not files:
                 raise RuntimeError(f"{counter} pass left no counter_collection.csv")
-            total, rows = 0.0, 0
+            total, rows, kept = 0.0, 0, []
             with open(files[0]) as f:
-                for r in csv.DictReader(f):
+                reader = csv.DictReader(f)
+                for r in reader:
                     if r["Counter_Name"] == counter and any(n in r["Kernel_Name"] for n in names):
                         total += float(r["Counter_Value"])
                         rows += 1
+                        kept.append(r)
+            if args.keep_counter_csv and kept:
+                with open(f"{args.keep_counter_csv}_pmc_{counter.lower()}.csv", "w", newline="") as f:
+                    w = csv.DictWriter(f, fieldnames=reader.fieldnames)
+                    w.writeheader()
+                    w.writerows(kept)
             if rows == 0:
                 raise RuntimeError(f"{counter} pass saw none of the kernels {names}")
             got[counter] = total * 1024.0 / launches

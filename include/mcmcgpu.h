@@ -63,7 +63,13 @@ typedef struct mcmcgpu_config {
    * state edge runs as a kernel of its own with many workgroups per chain
    * instead of inside the chain's own workgroup; 0 = the default (200 000). */
   uint32_t split_commit_min_poses;
-  uint32_t reserved; /* 0 */
+  /* Where the serial part of an update (selection, proposal, accept test; the reference's
+   * src/slam/mcmc_slam.hpp:339-418 outside the loop over readings) is compiled: 0 = the library
+   * chooses (compiled into the kernel when a launch has at most 256 chains, so that every chain
+   * has a CU to itself and its serial part is the launch's critical path; a called function
+   * otherwise, which keeps the registers of the loop over readings free); 1 = always called;
+   * 2 = compiled in whenever the workgroup has at most 256 lanes.  Results do not depend on it. */
+  uint32_t serial_program;
 } mcmcgpu_config;
 
 /* One Metropolis-Hastings step as recorded when trace_capacity > 0. */
@@ -444,6 +450,16 @@ int mcmcgpu_selftest_scan(int32_t device, uint32_t n, int32_t p, const int32_t* 
  * computes it (position::distance, src/planar_robot/position.hpp:33, by a
  * reciprocal-square-root seed and fused refinement steps instead of sqrt). */
 int mcmcgpu_selftest_range(int32_t device, uint32_t n, const double* dx, const double* dy, double* out);
+
+/* Self-test of the serial part's wavefront forms (used when it is compiled into the kernel,
+ * mcmcgpu_config.serial_program): n draws of the chain generator seeded with `seed`, kinds[i] = 0 a
+ * uniform (random_source::uniform, src/utility/random.hpp:25-31) or 1 a normal (:33-39), once by the
+ * one-lane code and once by the 64-lane code; and for each of n_search numbers u in [0, 1] the index
+ * bitree<double>::binary_search(total * u) (src/utility/bitree.hpp:302-321) finds in a tree of
+ * tree_n weights, by both forms.  The two outputs of each pair must be identical. */
+int mcmcgpu_selftest_wave(int32_t device, uint32_t seed, uint32_t n, const uint8_t* kinds, double* out_serial, double* out_wave,
+                          uint32_t tree_n, const double* weights, uint32_t n_search, const double* search_u,
+                          uint32_t* index_serial, uint32_t* index_wave);
 
 #ifdef __cplusplus
 }

@@ -73,6 +73,7 @@ struct ora_record {
   double proposed[3];
   double log_ratio;
   double log_likelihood;
+  double term_scale;
 };
 
 void* ora_world_new() { return new world(); }
@@ -307,6 +308,7 @@ void ora_chain_trace_get(void* p, int chain, std::uint32_t start, std::uint32_t 
     std::memcpy(out[i].proposed, r.proposed, sizeof r.proposed);
     out[i].log_ratio = r.log_ratio;
     out[i].log_likelihood = r.log_likelihood;
+    out[i].term_scale = r.term_scale;
   }
 }
 
@@ -318,6 +320,7 @@ double ora_chain_full_log_likelihood(void* p, int chain) {
 }
 
 std::uint64_t ora_chain_units(void* p, int chain) { return static_cast<world*>(p)->chains[chain]->units; }
+double ora_chain_min_accept_margin(void* p, int chain) { return static_cast<world*>(p)->chains[chain]->min_accept_margin; }
 
 void ora_chain_dims(void* p, int chain, std::uint32_t* T, std::uint32_t* F) {
   world& w = *static_cast<world*>(p);

@@ -43,6 +43,7 @@
 #include <fstream>
 #include <functional>
 #include <iostream>
+#include <limits>
 #include <map>
 #include <memory>
 #include <set>
@@ -833,6 +834,9 @@ struct step_record {
   double log_ratio;
   int accepted;
   double log_likelihood;  // chain LL after the step
+  // sum of the sizes of the log densities that log_ratio is the signed sum of: the scale on which two
+  // computations of it can be expected to agree (bookkeeping for the parity tests only)
+  double term_scale;
 };
 
 // src/slam/mcmc_slam.hpp:37-223 and the member definitions below it.
@@ -864,7 +868,18 @@ class mcmc_slam : public slam_data::listener, public slam_result {
   // reference's bit for bit); it exists so that the GPU library's tempering mode has a checker.
   double beta = 1.0;
   double tempered_obs_sum = 0.0;  // readings' part of the last state-edge log ratio
+  double term_scale = 0.0;        // see step_record::term_scale; reset at the start of every step
   std::uint64_t units = 0;    // executions of the loop body :487-502
+  // How close the accept test (:408) came to going the other way, over all steps so far: the smallest
+  // |normaliser * u - exp(accept_log_ratio)| / exp(accept_log_ratio).  Bookkeeping for the parity tests
+  // (an implementation whose exp / log differ in the last bits can only flip a decision whose
+  // margin is of that size); it changes no arithmetic of the sampler.
+  double min_accept_margin = std::numeric_limits<double>::infinity();
+  void note_margin(double lhs, double rhs) {
+    if (!(rhs > 0) || !std::isfinite(rhs) || !std::isfinite(lhs)) return;
+    const double m = std::fabs(lhs - rhs) / rhs;
+    if (m < min_accept_margin) min_accept_margin = m;
+  }
   std::vector<step_record>* trace = nullptr;
   unsigned steps_per_timestep = 0, end_steps = 0;  // the nested updater :200-222
 
@@ -918,6 +933,7 @@ class mcmc_slam : public slam_data::listener, public slam_result {
       const double old_ll = obs.second.log_likelihood_of(old_obs);
       obs_timestep = obs.first;
       log_ratio += new_ll - old_ll;
+      term_scale += std::fabs(new_ll) + std::fabs(old_ll);
       ++units;
     }
     return log_ratio;
@@ -925,7 +941,9 @@ class mcmc_slam : public slam_data::listener, public slam_result {
   // :433-466
   double state_edge_log_likelihood_ratio(std::size_t t, const pose& proposed) {
     const velocity_slip_model& dist = data->control(t);
-    double log_ratio = +dist.log_likelihood_of(proposed) - dist.log_likelihood_of(state_estimates.get(t));
+    const double new_control_ll = dist.log_likelihood_of(proposed), old_control_ll = dist.log_likelihood_of(state_estimates.get(t));
+    double log_ratio = +new_control_ll - old_control_ll;
+    term_scale = std::fabs(new_control_ll) + std::fabs(old_control_ll);
     tempered_obs_sum = 0.0;
     for (const auto& f : feature_estimates) {
       const auto& list = data->get_observations(f.id);
@@ -949,6 +967,7 @@ class mcmc_slam : public slam_data::listener, public slam_result {
   // :469-474
   double feature_edge_log_likelihood_ratio(std::size_t fi, const position& proposed) {
     const feature_estimate& f = feature_estimates[fi];
+    term_scale = 0.0;
     return obs_likelihood_ratio(f, f.parent_timestep, 0, data->get_observations(f.id).size(), proposed);
   }
 
@@ -973,14 +992,16 @@ class mcmc_slam : public slam_data::listener, public slam_result {
       normaliser += (new_weight - old_weight) / weight_sum;
       accept_log_ratio += new_log_weight - old_log_weight;
     }
-    const bool accept = normaliser * random.uniform() < std::exp(accept_log_ratio);
+    const double lhs = normaliser * random.uniform(), rhs = std::exp(accept_log_ratio);
+    note_margin(lhs, rhs);
+    const bool accept = lhs < rhs;
     if (accept) {
       state_estimates.set(t, proposed);
       state_weights.set(t, new_weight);
       log_likelihood += log_ratio;
       map_estimate.clear();
     }
-    if (trace) trace->push_back({0, t, {proposed.x, proposed.y, proposed.th}, log_ratio, accept, log_likelihood});
+    if (trace) trace->push_back({0, t, {proposed.x, proposed.y, proposed.th}, log_ratio, accept, log_likelihood, term_scale});
     return accept;
   }
   // :372-418, feature-edge instance (distribution = the observation at the
@@ -1008,14 +1029,16 @@ class mcmc_slam : public slam_data::listener, public slam_result {
       normaliser += (new_weight - old_weight) / weight_sum;
       accept_log_ratio += new_log_weight - old_log_weight;
     }
-    const bool accept = normaliser * random.uniform() < std::exp(accept_log_ratio);
+    const double lhs = normaliser * random.uniform(), rhs = std::exp(accept_log_ratio);
+    note_margin(lhs, rhs);
+    const bool accept = lhs < rhs;
     if (accept) {
       feature_estimates[fi].estimate = proposed;
       feature_weights.set(fi, new_weight);
       log_likelihood += log_ratio;
       map_estimate.clear();
     }
-    if (trace) trace->push_back({1, fi, {proposed.x, proposed.y, 0.0}, log_ratio, accept, log_likelihood});
+    if (trace) trace->push_back({1, fi, {proposed.x, proposed.y, 0.0}, log_ratio, accept, log_likelihood, term_scale});
     return accept;
   }
 

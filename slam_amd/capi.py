@@ -28,7 +28,7 @@ class Config(ctypes.Structure):
         ("range_bearing", ctypes.c_uint32),
         ("max_split_slices", ctypes.c_uint32),
         ("split_commit_min_poses", ctypes.c_uint32),
-        ("reserved", ctypes.c_uint32),
+        ("serial_program", ctypes.c_uint32),
     ]
 
 
@@ -109,6 +109,7 @@ EXPORTS = [
     "mcmcgpu_debug_phase_cycles",
     "mcmcgpu_selftest_scan",
     "mcmcgpu_selftest_range",
+    "mcmcgpu_selftest_wave",
 ]
 
 _lib = None
@@ -158,6 +159,23 @@ def selftest_range(dx, dy, device=0):
     return out
 
 
+def selftest_wave(seed, kinds, weights, search_u, device=0):
+    """The generator's and the weight tree's one-lane and 64-lane forms side by side; returns
+    (draws_serial, draws_wave, index_serial, index_wave)."""
+    lib = load_library()
+    kinds = np.ascontiguousarray(kinds, dtype=np.uint8)
+    weights = np.ascontiguousarray(weights, dtype=np.float64)
+    search_u = np.ascontiguousarray(search_u, dtype=np.float64)
+    ds, dw = np.zeros(kinds.size), np.zeros(kinds.size)
+    i_s, i_w = np.zeros(search_u.size, dtype=np.uint32), np.zeros(search_u.size, dtype=np.uint32)
+    rc = lib.mcmcgpu_selftest_wave(ctypes.c_int32(device), ctypes.c_uint32(seed), ctypes.c_uint32(kinds.size), _ptr(kinds),
+                                   _ptr(ds), _ptr(dw), ctypes.c_uint32(weights.size), _ptr(weights),
+                                   ctypes.c_uint32(search_u.size), _ptr(search_u), _ptr(i_s), _ptr(i_w))
+    if rc != 0:
+        raise RuntimeError(f"mcmcgpu_selftest_wave failed ({rc}): {lib.mcmcgpu_last_error(None).decode()}")
+    return ds, dw, i_s, i_w
+
+
 def selftest_scan(a, b, p, device=0):
     a = np.ascontiguousarray(a, dtype=np.int32)
     b = np.ascontiguousarray(b, dtype=np.int32)
@@ -200,11 +218,11 @@ class McmcGpu:
 
     def __init__(self, max_chains, max_timesteps, max_features, max_observations, device=0,
                  threads_per_chain=0, feature_uniform_first=True, trace_capacity=0, stream=None, range_bearing=False,
-                 max_split_slices=0, split_commit_min_poses=0):
+                 max_split_slices=0, split_commit_min_poses=0, serial_program=0):
         self.lib = load_library()
         cfg = Config(device, max_chains, max_timesteps, max_features, max_observations, threads_per_chain,
                      1 if feature_uniform_first else 0, trace_capacity, stream, 1 if range_bearing else 0, max_split_slices,
-                     split_commit_min_poses, 0)
+                     split_commit_min_poses, serial_program)
         self.h = ctypes.c_void_p()
         rc = self.lib.mcmcgpu_create(ctypes.byref(cfg), ctypes.byref(self.h))
         if rc != 0:

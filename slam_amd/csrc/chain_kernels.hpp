@@ -257,6 +257,9 @@ struct Shared {
   uint32_t segpre[kMaxSeg + 1];
   uint32_t seglo[kMaxSeg];
   double segw[kMaxSeg][4];  // old landmark (x,y), new landmark (x,y), world frame
+#ifdef MG_DIAG_RUN_RECORDS  // diagnostic builds (tools/window_probe.sh): timestep of a segment's first reading
+  uint32_t segt[kMaxSeg];
+#endif
   uint32_t wcount[kMaxWaves];
   double red[kMaxWaves];
 };
@@ -418,10 +421,17 @@ struct RatioStream {
   const double half_isd2;
   uint32_t cur = 0, seg_end, seg_base;
   double acc = 0.0;
+#ifdef MG_DIAG_RUN_RECORDS
+  uint32_t seg_tbase;
+#endif
 
   MG_DEV RatioStream(const Dev& d_, uint32_t c, const Shared& S_, uint32_t nseg)
       : d(d_), S(S_), pxy(d_.pxy + size_t(c) * (d_.Tcap + 1)), total(S_.segpre[nseg]), stride(blockDim.x),
-        half_isd2(0.5 * d_.usig_inv * d_.usig_inv), seg_end(S_.segpre[1]), seg_base(S_.seglo[0]) {}
+        half_isd2(0.5 * d_.usig_inv * d_.usig_inv), seg_end(S_.segpre[1]), seg_base(S_.seglo[0]) {
+#ifdef MG_DIAG_RUN_RECORDS
+    seg_tbase = S_.segt[0];
+#endif
+  }
 
   MG_DEV void request_records(uint32_t i0, Recs& r) {
     if (i0 >= total) return;
@@ -435,22 +445,34 @@ struct RatioStream {
             seg_end = S.segpre[cur + 1];
           } while (i >= seg_end);
           seg_base = S.seglo[cur] - S.segpre[cur];
+#ifdef MG_DIAG_RUN_RECORDS
+          seg_tbase = S.segt[cur] - S.segpre[cur];
+#endif
         }
         r.o[u] = seg_base + i;
       } else {
         r.o[u] = S.seglo[0];
       }
       r.sg[u] = cur;
+#ifdef MG_DIAG_RUN_RECORDS
+      // what a stream over runs of consecutive timesteps would do: the timestep is arithmetic on the
+      // segment (here: as if every segment were one run -- wrong results), the record 8 bytes
+      r.t[u] = i < total ? min(seg_tbase + i, d.T) : 0u;
+#endif
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-#ifdef MG_DIAG_RECORD_WINDOW  // diagnostic builds (tools/window_probe.sh): wrong results, known traffic
+#if defined(MG_DIAG_RUN_RECORDS)
+      r.mu[u] = d.osd[r.o[u]];  // an 8-byte array with one entry per reading stands in for the ranges
+#elif defined(MG_DIAG_RECORD_WINDOW)  // diagnostic builds (tools/window_probe.sh): wrong results, known traffic
       const StreamRec rec = d.osr[r.o[u] & 4095u];
-#else
-      const StreamRec rec = d.osr[r.o[u]];
-#endif
       r.t[u] = rec.t;
       r.mu[u] = rec.mu;
+#else
+      const StreamRec rec = d.osr[r.o[u]];
+      r.t[u] = rec.t;
+      r.mu[u] = rec.mu;
+#endif
     }
   }
   MG_DEV void request_poses(uint32_t i0, const Recs& r, Poses& p) {
@@ -897,6 +919,9 @@ MG_DEV double eval_state_edge(const Dev& d, uint32_t c, Shared& S, uint32_t t, c
     S.segw[tid][1] = w.y;
     S.segw[tid][2] = wn.x;
     S.segw[tid][3] = wn.y;
+#ifdef MG_DIAG_RUN_RECORDS
+    S.segt[tid] = len ? d.otime[slo] : 0u;
+#endif
     return len;
   };
   auto stream = [&](uint32_t len, uint32_t nseg) {
@@ -1041,7 +1066,8 @@ MG_DEV Reading load_reading(const Dev& d, uint32_t o) {
 // proposal_dist::operator() of the reading's model.  Range only
 // (range_bearing_model.hpp:155-159): polar(N(mu, sigma), U 2 pi), draw order by flag.  Range and
 // bearing (:84-86): inv_observe of two normals drawn in index order (random.hpp:94-100).
-MG_DEV Vec2 propose_landmark(const Dev& d, Shared& S, const Reading& m);
+template <class R>
+MG_DEV Vec2 propose_landmark(const Dev& d, R& rng, const Reading& m);
 
 MG_DEV void load_control(const Dev& d, uint32_t t, double mu[3], double sd[3], double& log_det) {
 #pragma unroll
@@ -1070,20 +1096,21 @@ MG_DEV void write_trace(const Dev& d, uint32_t c, Shared& S, int kind, uint32_t 
   d.trace_n[c] = n + 1;
 }
 
-MG_DEV Vec2 propose_landmark(const Dev& d, Shared& S, const Reading& m) {
+template <class R>
+MG_DEV Vec2 propose_landmark(const Dev& d, R& rng, const Reading& m) {
   if (m.bearing) {
-    double v0 = rng_normal(S.rng), v1 = rng_normal(S.rng);
+    double v0 = rng.normal(), v1 = rng.normal();
     v0 = v0 * m.sd + m.mu;
     v1 = v1 * m.bsd + m.bmu;
     return polar(v0, v1);
   }
   double r, u;
   if (d.uniform_first) {
-    u = rng_uniform(S.rng);
-    r = rng_normal(S.rng) * m.sd + m.mu;
+    u = rng.uniform();
+    r = rng.normal() * m.sd + m.mu;
   } else {
-    r = rng_normal(S.rng) * m.sd + m.mu;
-    u = rng_uniform(S.rng);
+    r = rng.normal() * m.sd + m.mu;
+    u = rng.uniform();
   }
   return polar(r, u * 2 * kPi);
 }
@@ -1122,7 +1149,17 @@ MG_DEV void refresh_totals(const Dev& d, uint32_t c, Shared& S) {
 
 // Selection and proposal of one update (mcmc_slam.hpp:339-368, :375-382).
 // Returns false when nothing can be updated (both weight totals zero, :345).
-MG_DEV bool driver_begin_update(const Dev& d, uint32_t c, Shared& S) {
+// Index draw on a weight tree: the serial descent, or the wavefront's when all 64 lanes run this code.
+template <class R>
+MG_DEV uint32_t draw_index(const wt::Cached& tree, uint32_t n, double value) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (R::kWave) return wt::search_wave(tree, n, value);
+#endif
+  return wt::search(tree, n, value);
+}
+
+template <class R>
+MG_DEV bool driver_begin_update(const Dev& d, uint32_t c, Shared& S, R& rng) {
   const wt::Cached sw = state_tree(d, c, S), fw = landmark_tree(d, c, S);
   MG_MARK_BEGIN();
   refresh_totals(d, c, S);
@@ -1130,12 +1167,12 @@ MG_DEV bool driver_begin_update(const Dev& d, uint32_t c, Shared& S) {
   if (Ws == 0 && Wf == 0) return false;
   uint32_t retry = 0;
   MG_MARK(S, 8);
-  const double which = rng_uniform(S.rng);
+  const double which = rng.uniform();
   MG_MARK(S, 9);
   if ((Ws + Wf) * which < Ws) {
     uint32_t t;
     do {
-      t = wt::search(sw, S.Tcur, Ws * rng_uniform(S.rng));
+      t = draw_index<R>(sw, S.Tcur, Ws * rng.uniform());
     } while (t >= S.Tcur && ++retry < kMaxRetry);
     if (t >= S.Tcur) {
       S.failed = 1;
@@ -1146,7 +1183,7 @@ MG_DEV bool driver_begin_update(const Dev& d, uint32_t c, Shared& S) {
     load_control(d, t, mu, sd, ld);
     // the current relative pose's log density is kept from when that pose was set
     const double old_pll = d.clp[size_t(c) * d.Tcap + t];
-    for (int i = 0; i < 3; ++i) v[i] = rng_normal(S.rng);
+    for (int i = 0; i < 3; ++i) v[i] = rng.normal();
     for (int i = 0; i < 3; ++i) v[i] = v[i] * sd[i] + mu[i];
     MG_MARK(S, 11);
     const Pose q = control_inv_observe(v);
@@ -1162,7 +1199,7 @@ MG_DEV bool driver_begin_update(const Dev& d, uint32_t c, Shared& S) {
   } else {
     uint32_t f;
     do {
-      f = wt::search(fw, S.nf, Wf * rng_uniform(S.rng));
+      f = draw_index<R>(fw, S.nf, Wf * rng.uniform());
     } while (f >= S.nf && ++retry < kMaxRetry);
     if (f >= S.nf) {
       S.failed = 1;
@@ -1170,7 +1207,7 @@ MG_DEV bool driver_begin_update(const Dev& d, uint32_t c, Shared& S) {
     }
     const size_t fi = size_t(c) * d.Fcap + f;
     const Reading m = load_reading(d, d.foff[f] + d.fpar[fi]);
-    const Vec2 q = propose_landmark(d, S, m);
+    const Vec2 q = propose_landmark(d, rng, m);
     S.new_pll = reading_proposal_log_pdf(m, q);
     S.old_pll = reading_proposal_log_pdf(m, Vec2{d.fex[fi], d.fey[fi]});
     S.op = OP_EVAL_FEATURE;
@@ -1188,7 +1225,8 @@ MG_DEV bool driver_begin_update(const Dev& d, uint32_t c, Shared& S) {
 // The rest of mcmc_slam::update(EdgeType&&, bool) (:385-418) once the
 // observation part of the log ratio is known.  Returns the accept decision;
 // the pose table of an accepted state edge is moved afterwards by all lanes.
-MG_DEV bool driver_finish_update(const Dev& d, uint32_t c, Shared& S, double obs_ratio) {
+template <class R>
+MG_DEV bool driver_finish_update(const Dev& d, uint32_t c, Shared& S, R& rng, double obs_ratio) {
   const bool is_state = (S.op == OP_EVAL_STATE);
   const double dim = is_state ? 3.0 : 2.0;
   const double proposal_log_ratio = S.new_pll - S.old_pll;
@@ -1211,9 +1249,9 @@ MG_DEV bool driver_finish_update(const Dev& d, uint32_t c, Shared& S, double obs
     accept_log_ratio += new_log_weight - old_log_weight;
   }
 #ifdef MG_DIAG_REJECT_ALL  // diagnostic builds: the chains stay where they are whatever the streams computed
-  const bool accept = (normaliser * rng_uniform(S.rng) < exp(accept_log_ratio)) && false;
+  const bool accept = (normaliser * rng.uniform() < exp(accept_log_ratio)) && false;
 #else
-  const bool accept = normaliser * rng_uniform(S.rng) < exp(accept_log_ratio);
+  const bool accept = normaliser * rng.uniform() < exp(accept_log_ratio);
 #endif
   if (accept) {
     if (is_state) {
@@ -1237,7 +1275,8 @@ MG_DEV bool driver_finish_update(const Dev& d, uint32_t c, Shared& S, double obs
 
 // One arrival during growth (mcmc_slam.hpp:283-331).  Returns true when a
 // re-parenting update was posted and needs the workgroup.
-MG_DEV bool driver_arrival(const Dev& d, uint32_t c, Shared& S, uint32_t o) {
+template <class R>
+MG_DEV bool driver_arrival(const Dev& d, uint32_t c, Shared& S, R& rng, uint32_t o) {
   const ObsRec rec = d.orec[o];
   const uint32_t f = rec.f;
   const size_t fi = size_t(c) * d.Fcap + f;
@@ -1251,7 +1290,7 @@ MG_DEV bool driver_arrival(const Dev& d, uint32_t c, Shared& S, uint32_t o) {
     } else if (m.bearing) {  // proposal_dist::initial_value, range_bearing_model.hpp:93-95: no draw at all
       est = polar(m.mu, m.bmu);
     } else {
-      const double u = (d.init_u && f < d.n_init_u) ? d.init_u[f] : rng_uniform(S.rng);
+      const double u = (d.init_u && f < d.n_init_u) ? d.init_u[f] : rng.uniform();
       est = polar(mu, u * 2 * kPi);
     }
     d.fex[fi] = est.x;
@@ -1281,7 +1320,7 @@ MG_DEV bool driver_arrival(const Dev& d, uint32_t c, Shared& S, uint32_t o) {
     d.fex[fi] = est.x;
     d.fey[fi] = est.y;
     // update(feature_edge, false), :320
-    const Vec2 q = propose_landmark(d, S, m);
+    const Vec2 q = propose_landmark(d, rng, m);
     S.new_pll = reading_proposal_log_pdf(m, q);
     S.old_pll = reading_proposal_log_pdf(m, est);
     S.op = OP_EVAL_FEATURE;
@@ -1314,7 +1353,8 @@ MG_DEV void driver_report(const Dev& d, uint32_t c, Shared& S) {
 
 // Runs lane 0's program until it needs the workgroup (a request is posted in
 // S.op) or is finished (S.op = OP_END).
-MG_DEV void driver_advance(const Dev& d, uint32_t c, Shared& S) {
+template <class R>
+MG_DEV void driver_advance(const Dev& d, uint32_t c, Shared& S, R& rng) {
   for (;;) {
     if (S.failed) {
       S.op = OP_END;
@@ -1338,7 +1378,7 @@ MG_DEV void driver_advance(const Dev& d, uint32_t c, Shared& S) {
         MG_MARK_BEGIN();
         while (S.arr < S.arr_end) {
           const uint32_t o = d.tobs[S.arr++];
-          if (driver_arrival(d, c, S, o)) {
+          if (driver_arrival(d, c, S, rng, o)) {
             MG_MARK(S, 15);
             return;
           }
@@ -1352,7 +1392,7 @@ MG_DEV void driver_advance(const Dev& d, uint32_t c, Shared& S) {
         while (S.steps_left > 0) {
           --S.steps_left;
           ++S.n_upd;
-          if (driver_begin_update(d, c, S)) return;
+          if (driver_begin_update(d, c, S, rng)) return;
         }
         S.stage = ST_NEXT;
         break;
@@ -1370,7 +1410,7 @@ MG_DEV void driver_advance(const Dev& d, uint32_t c, Shared& S) {
           --S.end_left;
           ++S.n_upd;
           ++S.end_done;
-          if (driver_begin_update(d, c, S)) {
+          if (driver_begin_update(d, c, S, rng)) {
             S.end_inflight = 1;
             return;
           }
@@ -1467,16 +1507,15 @@ MG_DEV double inline_eval(DevArgs dp, SharedLds sp, uint32_t c, int op, uint32_t
 // whose evaluation has just come back (`r`; accept test and bookkeeping), then -- unless an accepted
 // state edge first needs all lanes for the pose table (OP_COMMIT) -- on to the next request.  One
 // call per update instead of two: a call costs a lone lane the save and reload of its registers.
-MG_PIECE void piece_step(DevArgs dp, SharedLds sp, uint32_t c, double r) {
-  const Dev& d = *(const Dev*)dp;
-  Shared& S = *(Shared*)sp;
+template <class R>
+MG_DEV void step_with(const Dev& d, uint32_t c, Shared& S, R& rng, double r) {
   if (S.awaiting) {
     S.awaiting = 0;
 #ifdef MG_PHASE_TIMING
     const long long tf0 = clock64();
 #endif
     const uint32_t idx = S.idx;
-    const bool accept = driver_finish_update(d, c, S, r);
+    const bool accept = driver_finish_update(d, c, S, rng, r);
     S.accept = accept ? 1 : 0;
     if (S.pending == PEND_UPDATE) {
       if (accept) ++S.n_acc;
@@ -1499,9 +1538,37 @@ MG_PIECE void piece_step(DevArgs dp, SharedLds sp, uint32_t c, double r) {
       return;
     }
   }
-  driver_advance(d, c, S);
+  driver_advance(d, c, S, rng);
   if (S.op == OP_EVAL_STATE || S.op == OP_EVAL_FEATURE) S.awaiting = 1;
 }
+
+// WAVE: the body is run by all 64 lanes of a wavefront on the same data (every lane computes and
+// stores the same values), which lets the generator's window and the weight trees' descents use
+// the lanes (WaveRng, wt::search_wave); otherwise by one lane.  Same results either way.
+template <bool WAVE>
+MG_DEV void step_body(DevArgs dp, SharedLds sp, uint32_t c, double r) {
+  const Dev& d = *(const Dev*)dp;
+  Shared& S = *(Shared*)sp;
+#ifdef MG_PHASE_TIMING
+  const long long t_in = clock64();
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (WAVE) {
+    WaveRng rng(S.rng);
+    step_with(d, c, S, rng, r);
+    rng.flush();
+  } else
+#endif
+  {
+    SerialRng rng{S.rng};
+    step_with(d, c, S, rng, r);
+  }
+#ifdef MG_PHASE_TIMING
+  S.phase[7] += clock64() - t_in;  // slot 7: first to last instruction of the body (the call is the rest)
+#endif
+}
+
+MG_PIECE void piece_step(DevArgs dp, SharedLds sp, uint32_t c, double r) { step_body<false>(dp, sp, c, r); }
 
 MG_PIECE void piece_commit(DevArgs dp, SharedLds sp, uint32_t c, uint32_t idx, double qx, double qy, double qth,
                            uint32_t Tcur) {
@@ -1525,8 +1592,11 @@ MG_PIECE void piece_commit(DevArgs dp, SharedLds sp, uint32_t c, uint32_t idx, d
 struct TreeTops {
   uint32_t sw_n, sw_shift, fw_n, fw_shift;
 };
-template <bool RB>
-__global__ void advance_kernel(Dev d, uint32_t first_tn, uint32_t Tcur0, uint32_t upto, uint32_t steps_per_ts,
+// SOLO: the serial program compiled into the kernel as well, for launches of so few chains that a chain
+// has its CU to itself and the serial program IS the launch's critical path (one mcmc_slam instance on
+// a Plaza-sized log): no call, no registers saved and reloaded around it.
+template <bool RB, bool SOLO = false>
+__global__ void __launch_bounds__(SOLO ? 256 : 1024) advance_kernel(Dev d, uint32_t first_tn, uint32_t Tcur0, uint32_t upto, uint32_t steps_per_ts,
                                uint32_t end_steps, uint32_t grow, TreeTops tops) {
   __shared__ Shared S;
   extern __shared__ double tree_tops[];
@@ -1560,7 +1630,11 @@ __global__ void advance_kernel(Dev d, uint32_t first_tn, uint32_t Tcur0, uint32_
   double r = 0.0;
   for (;;) {
     MG_STAMP(td0);
-    if (threadIdx.x == 0) piece_step(dp, sp, c, r);
+    if (SOLO) {
+      if (threadIdx.x < 64) step_body<true>(dp, sp, c, r);  // the first wavefront, all lanes on the same data
+    } else {
+      if (threadIdx.x == 0) piece_step(dp, sp, c, r);
+    }
     __syncthreads();
     MG_STAMP(td1);
     MG_PHASE_ADD(S, 0, td0, td1);
@@ -1577,6 +1651,10 @@ __global__ void advance_kernel(Dev d, uint32_t first_tn, uint32_t Tcur0, uint32_
       continue;
     }
     r = inline_eval<RB>(dp, sp, c, op, idx, qx, qy, qth, nf);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the sum is valid in lane 0; the first wavefront's lanes all run the serial program on it
+    if (SOLO) r = wt::readlane_f64(r, 0);
+#endif
     MG_STAMP(te1);
     if (op != OP_EVAL_STATE) MG_PHASE_ADD(S, 3, td1, te1);
   }
@@ -1584,10 +1662,6 @@ __global__ void advance_kernel(Dev d, uint32_t first_tn, uint32_t Tcur0, uint32_
   MG_PHASE_ADD(S, 6, tk0, tk1);
 #ifdef MG_PHASE_TIMING
   if (threadIdx.x == 0) {
-    // slot 7: on which SIMD of its CU the driver's wavefront runs, four 16-bit counters
-    // (HW_ID register, SIMD_ID = bits 5:4)
-    const uint32_t simd = __builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11));
-    S.phase[7] = 1ll << (16 * (simd & 3));
     for (int i = 0; i < 16; ++i) atomicAdd(&g_phase_cycles[i], (unsigned long long)S.phase[i]);
   }
 #endif
@@ -1664,7 +1738,8 @@ __global__ void split_ends_kernel(Dev d_by_value, uint32_t Tcur, uint32_t slices
         const double r = slices_sum;
         S.n_units = d.ctl[c].total;
         if (S.op == OP_EVAL_STATE) S.n_state = 1;
-        const bool accept = driver_finish_update(d, c, S, r);
+        SerialRng rng{S.rng};
+        const bool accept = driver_finish_update(d, c, S, rng, r);
         S.accept = accept ? 1 : 0;
         if (accept) S.n_acc = 1;
         S.pending = PEND_NONE;
@@ -1704,7 +1779,8 @@ __global__ void split_ends_kernel(Dev d_by_value, uint32_t Tcur, uint32_t slices
   __syncthreads();
   if (threadIdx.x == 0) {
     S.op = OP_END;
-    if (begin && !S.failed && !d.errflag[c] && !driver_begin_update(d, c, S)) S.op = OP_END;
+    SerialRng rng{S.rng};
+    if (begin && !S.failed && !d.errflag[c] && !driver_begin_update(d, c, S, rng)) S.op = OP_END;
     shared_to_ctl(d, c, S);
   }
   chain_state_store(d, c, S);
@@ -2040,6 +2116,21 @@ constexpr int kScanLanes = 256, kScanPerLane = 4;          // tile = 1024 poses
 constexpr uint32_t kScanTargetGroups = 1024;               // workgroups a rebuild should offer the GPU
 constexpr uint32_t kScanMinSegmentTiles = 4;               // no segment shorter than this many tiles
 
+// Four relative-pose components in a row as two 16-byte loads (8-byte aligned: a chain's slice may start
+// on an odd element); element by element the compiler issues four 8-byte loads whose lanes are 32 bytes apart.
+struct __attribute__((packed, aligned(8))) Double2 {
+  double a, b;
+};
+MG_DEV void load4(const double* __restrict__ p, double out[4]) {
+  const Double2 lo = *reinterpret_cast<const Double2*>(p), hi = *reinterpret_cast<const Double2*>(p + 2);
+  out[0] = lo.a;
+  out[1] = lo.b;
+  out[2] = hi.a;
+  out[3] = hi.b;
+}
+
+// (No occupancy bound: held to 128 registers for a fourth workgroup per CU the kernel spills and
+// runs a quarter slower.)
 template <bool WRITE>
 __global__ void __launch_bounds__(kScanLanes) scan_chain_kernel(ScanArgs a) {
   __shared__ PoseCS stage[2][kScanMaxWaves];
@@ -2058,8 +2149,17 @@ __global__ void __launch_bounds__(kScanLanes) scan_chain_kernel(ScanArgs a) {
     pxy[0] = PoseXY{0.0, 0.0};
     pth[0] = 0.0;
   }
+  static_assert(kScanPerLane == 4, "the row loader below fetches four elements");
   carry = chained_scan<kScanPerLane>(
       op, lo, hi, carry, [&](uint32_t i) { return Pose{rx[i], ry[i], rth[i]}; },
+      [&](uint32_t first, Pose* out) {
+        double x[4], y[4], th[4];
+        load4(rx + first, x);
+        load4(ry + first, y);
+        load4(rth + first, th);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out[k] = Pose{x[k], y[k], th[k]};
+      },
       [&](uint32_t i, const PoseCS& v) {
         if (WRITE) {
           pxy[i + 1] = PoseXY{v.x, v.y};
@@ -2492,11 +2592,58 @@ __global__ void __launch_bounds__(kScanLanes) scan_affine_kernel(uint32_t n, int
   const AffineOp op{p};
   chained_scan<kScanPerLane>(
       op, 0u, n, op.identity(), [&](uint32_t i) { return Affine{a[i], b[i]}; },
+      row_by_elements<kScanPerLane, Affine>([&](uint32_t i) { return Affine{a[i], b[i]}; }),
       [&](uint32_t i, const Affine& v) {
         oa[i] = v.a;
         ob[i] = v.b;
       },
       stage);
+}
+
+// Self-tests of the wavefront forms of the generator and of the weight-tree descent against the serial
+// ones they must equal bit for bit.  One workgroup of 64 lanes each.  kinds[i]: 0 = uniform, 1 = normal.
+struct SelftestLds {
+  double pad[16];  // the generator's state sits where a chain's does: not at the start of the workgroup's LDS
+  RngState rng;
+};
+__global__ void __launch_bounds__(64) serial_draws_selftest_kernel(uint32_t seed, uint32_t n, const uint8_t* kinds, double* out) {
+  __shared__ SelftestLds L;
+  if (threadIdx.x == 0) {
+    rng_seed(L.rng, seed);
+    SerialRng r{L.rng};
+    for (uint32_t i = 0; i < n; ++i) out[i] = kinds[i] ? r.normal() : r.uniform();
+  }
+}
+__global__ void __launch_bounds__(64) wave_draws_selftest_kernel(uint32_t seed, uint32_t n, const uint8_t* kinds, double* out) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the wavefront forms exist in device code only
+  __shared__ SelftestLds L;
+  if (threadIdx.x == 0) rng_seed(L.rng, seed);
+  __syncthreads();
+  for (uint32_t i0 = 0; i0 < n; i0 += 7) {  // a fresh window object every few draws, as one per update
+    WaveRng r(L.rng);
+    for (uint32_t i = i0; i < n && i < i0 + 7; ++i) {
+      const double v = kinds[i] ? r.normal() : r.uniform();
+      if (threadIdx.x == 0) out[i] = v;
+    }
+    r.flush();
+  }
+#endif
+}
+// nodes: the tree in the reference's layout (built on the host); index pairs out: serial, wave
+__global__ void __launch_bounds__(64) search_selftest_kernel(uint32_t tree_n, double* nodes, uint32_t ns, const double* us,
+                                                             uint32_t* is, uint32_t* iw) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const wt::Plain t{nodes};
+  const double total = wt::total(t, tree_n);
+  for (uint32_t j = 0; j < ns; ++j) {
+    const double value = total * us[j];
+    const uint32_t s = wt::search(t, tree_n, value), w = wt::search_wave(t, tree_n, value);
+    if (threadIdx.x == 0) {
+      is[j] = s;
+      iw[j] = w;
+    }
+  }
+#endif
 }
 
 }  // namespace mg

@@ -305,6 +305,77 @@ MG_DEV uint32_t search(const N& node, uint32_t n, double value) {
   }
   return hi;
 }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+MG_DEV double readlane_f64(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+// search() for a whole wavefront whose 64 lanes all hold the same arguments (and get the same
+// result): the descent's comparisons are sequential -- each decides which node is probed next --
+// but there are only two outcomes each, so lane L plays the next six comparisons ASSUMING the
+// outcomes that the bits of L spell.  Which nodes a lane probes then depends on its lane number
+// alone: all six loads go out together, and the additions and comparisons that follow are the
+// serial code's, operation for operation, on the one lane whose assumptions all hold.  Six levels
+// cost one memory latency instead of six.
+template <class N>
+MG_DEV uint32_t search_wave(const N& node, uint32_t n, double value) {
+  if (n == 0 || value < node.ld(0)) return 0;
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t lo = 0, hi = n;
+  double origin = node.ld(0);
+  constexpr int kLevels = 6;
+  // (a 32-bit index has at most 32 levels: the bound only keeps a wavefront whose lanes disagree --
+  // which the callers rule out -- from spinning)
+  for (int round = 0; round < 6 && lo + 1 < hi; ++round) {
+    uint32_t mids[kLevels];
+    double at[kLevels];
+    {
+      uint32_t l = lo, h = hi;
+#pragma unroll
+      for (int k = 0; k < kLevels; ++k) {
+        mids[k] = 0xFFFFFFFFu;
+        at[k] = 0.0;
+        if (l + 1 < h) {
+          const uint32_t mid = child_containing(l, h - 1);
+          mids[k] = mid;
+          at[k] = node.ld(mid);
+          if ((lane >> k) & 1u)
+            l = mid;
+          else
+            h = mid;
+        }
+      }
+    }
+    uint32_t l = lo, h = hi;
+    double o = origin;
+    bool consistent = true;
+#pragma unroll
+    for (int k = 0; k < kLevels; ++k) {
+      const bool assumed = (lane >> k) & 1u;
+      if (mids[k] != 0xFFFFFFFFu) {
+        const double s = o + at[k];
+        const bool right = !(value < s);  // the serial code's `else` branch: lo = mid, origin += at_mid
+        consistent = consistent && (right == assumed);
+        if (assumed) {
+          l = mids[k];
+          o = s;
+        } else {
+          h = mids[k];
+        }
+      } else {
+        consistent = consistent && !assumed;  // the descent has ended: one lane (all further bits 0) carries it
+      }
+    }
+    const unsigned long long mask = __ballot(consistent);
+    if (mask == 0) return n;  // cannot happen for finite weights; the caller treats n as "draw again"
+    const int src = __ffsll((long long)mask) - 1;  // exactly one lane
+    lo = uint32_t(__builtin_amdgcn_readlane(int(l), src));
+    hi = uint32_t(__builtin_amdgcn_readlane(int(h), src));
+    origin = readlane_f64(o, src);
+  }
+  return hi;
+}
+#endif
 }  // namespace wt
 
 // ---- random stream -----------------------------------------------------------
@@ -371,6 +442,139 @@ MG_DEV double rng_normal(RngState& r) {
   r.has_saved = 1;
   return y * mult;
 }
+
+// The stream as the serial code above draws it, behind the interface the sampler's serial part uses.
+struct SerialRng {
+  static constexpr bool kWave = false;
+  RngState& st;
+  MG_DEV double uniform() { return rng_uniform(st); }
+  MG_DEV double normal() { return rng_normal(st); }
+  MG_DEV void flush() {}
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// The twist of rng_refill by a whole wavefront, 64 words at a time.  Word i is made of the OLD
+// words i and i + 1 and of word i + 397 (mod 624), old for i < 227 and new from there on: inside
+// a block of 64 every lane reads before any lane writes (one instruction does each for all
+// lanes), word i + 397 lies in a block not yet rewritten, and word i - 227 in one already done.
+MG_DEV void rng_refill_wave(RngState& r) {
+  const int lane = threadIdx.x & 63;
+  for (int i0 = 0; i0 < 624; i0 += 64) {
+    const int i = i0 + lane;
+    uint32_t v = 0;
+    if (i < 624) {
+      const int i1 = (i + 1 == 624) ? 0 : i + 1;
+      const int im = (i + 397 >= 624) ? i + 397 - 624 : i + 397;
+      const uint32_t y = (r.mt[i] & 0x80000000u) | (r.mt[i1] & 0x7fffffffu);
+      v = r.mt[im] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    // the lanes exchange words through LDS: to the compiler one lane's loads and another lane's
+    // stores are unrelated, so the order "all loads of a block, then its stores, then the next
+    // block's loads" has to be spelled out
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (i < 624) r.mt[i] = v;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  r.idx = 0;
+}
+
+// The same stream for a wavefront whose 64 lanes run the sampler's serial part together (same
+// data in every lane).  A window of up to 64 tempered outputs is taken at once, one per lane, and
+// handed out with v_readlane; the polar method's trials -- sequential in the reference, the first
+// one inside the unit circle wins -- are evaluated side by side, one per lane, on the outputs each
+// trial would have drawn, and the first accepted one is taken.  Every value is the serial code's:
+// same outputs in the same order, same arithmetic per trial.
+struct WaveRng {
+  static constexpr bool kWave = true;
+  RngState& st;
+  uint32_t win = 0;          // lane L: output base + L of the current block of 624 (valid for L < n)
+  int base, n = 0, pos = 0;  // the window starts at word `base`, holds n outputs, `pos` of them are used
+  int has_saved;
+  double saved;
+  MG_DEV explicit WaveRng(RngState& s) : st(s), base(s.idx), has_saved(s.has_saved), saved(s.saved) {}
+  MG_DEV void flush() {
+    st.idx = base + pos;
+    st.has_saved = has_saved;
+    st.saved = saved;
+  }
+  MG_DEV void load_window() {
+    int idx = base + pos;
+    if (idx >= 624) {
+      rng_refill_wave(st);
+      idx = 0;
+    }
+    base = idx;
+    pos = 0;
+    n = 624 - idx < 64 ? 624 - idx : 64;
+    const int lane = threadIdx.x & 63;
+    uint32_t y = st.mt[idx + lane < 624 ? idx + lane : 623];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    win = y;
+  }
+  MG_DEV uint32_t next() {
+    if (pos >= n) load_window();
+    const uint32_t v = uint32_t(__builtin_amdgcn_readlane(int(win), __builtin_amdgcn_readfirstlane(pos)));
+    ++pos;
+    return v;
+  }
+  static MG_DEV double canonical(uint32_t lo32, uint32_t hi32) {  // generate_canonical<double,53>, as rng_uniform
+    double ret = (double(lo32) + double(hi32) * 4294967296.0) / 18446744073709551616.0;
+    if (ret >= 1.0) ret = 0x1.fffffffffffffp-1;
+    return ret;
+  }
+  MG_DEV double uniform() {
+    const uint32_t lo32 = next(), hi32 = next();
+    return canonical(lo32, hi32);
+  }
+  MG_DEV double normal() {
+    if (has_saved) {
+      has_saved = 0;
+      return saved;
+    }
+    const int lane = threadIdx.x & 63;
+    // (a trial fails with probability 1 - pi/4; the bound only keeps corrupted state from spinning)
+    for (int guard = 0; guard < 4096; ++guard) {
+      if (pos >= n) load_window();
+      int trials = (n - pos) >> 2;  // whole trials (four outputs each) left in the window
+      if (trials == 0) {  // the next trial straddles the window's end: drawn the serial way
+        const double x = 2.0 * uniform() - 1.0;
+        const double y = 2.0 * uniform() - 1.0;
+        const double r2 = x * x + y * y;
+        if (r2 > 1.0 || r2 == 0.0) continue;
+        const double mult = sqrt(-2 * log(r2) / r2);
+        saved = x * mult;
+        has_saved = 1;
+        return y * mult;
+      }
+      if (trials > 16) trials = 16;
+      const int at = (pos + 4 * lane) & 63;  // lanes beyond `trials` read something and are ignored
+      const uint32_t a0 = uint32_t(__shfl(int(win), at)), a1 = uint32_t(__shfl(int(win), (at + 1) & 63));
+      const uint32_t b0 = uint32_t(__shfl(int(win), (at + 2) & 63)), b1 = uint32_t(__shfl(int(win), (at + 3) & 63));
+      const double x = 2.0 * canonical(a0, a1) - 1.0;
+      const double y = 2.0 * canonical(b0, b1) - 1.0;
+      const double r2 = x * x + y * y;
+      const bool ok = lane < trials && !(r2 > 1.0 || r2 == 0.0);
+      const unsigned long long mask = __ballot(ok);
+      if (mask == 0) {  // none of them inside the circle: all consumed
+        pos += 4 * trials;
+        continue;
+      }
+      const int first = __ffsll((long long)mask) - 1;
+      const double mult = sqrt(-2 * log(r2) / r2);  // every lane for its own trial; one is read
+      saved = wt::readlane_f64(x * mult, first);
+      has_saved = 1;
+      pos += 4 * (first + 1);
+      return wt::readlane_f64(y * mult, first);
+    }
+    return __builtin_nan("");
+  }
+};
+#endif
 
 }  // namespace mg
 

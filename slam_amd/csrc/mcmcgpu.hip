@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <set>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -40,7 +41,7 @@ struct mcmcgpu_ctx {
   double* scratch = nullptr;  // readout staging: max(3*(Tcap+1), ...) doubles
   size_t scratch_doubles = 0;
   uint32_t nthreads = 256;
-  size_t advance_lds_allowed = 48 * 1024;  // dynamic LDS advance_kernel may be launched with so far
+  std::set<const void*> advance_lds_raised;  // advance_kernel variants whose dynamic LDS limit has been raised above 48 KB
   // host-side bookkeeping
   uint32_t chains = 0;
   bool problem_loaded = false;
@@ -346,6 +347,7 @@ constexpr size_t kStaticScratchBytes = (size_t(kScanTargetGroups) + kStaticScanC
 static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
 
 constexpr int kMaxDevices = 64;
+constexpr uint32_t kSoloMaxChains = 256;  // chains (= CUs) up to which a launch takes advance_kernel's SOLO variant
 std::mutex g_static_scratch_mutex;
 void* g_static_scratch[kMaxDevices] = {};
 
@@ -365,7 +367,11 @@ hipError_t static_scratch_on(int device, void** out) {
 }
 
 // LDS of a CU and what advance_kernel declares statically (its Shared block, rounded up).
+#ifdef MG_DIAG_RUN_RECORDS
+constexpr size_t kLdsPerCu = 160 * 1024, kAdvanceStaticLds = 20 * 1024;  // the diagnostic build's extra table
+#else
 constexpr size_t kLdsPerCu = 160 * 1024, kAdvanceStaticLds = 18 * 1024;
+#endif
 static_assert(sizeof(Shared) <= kAdvanceStaticLds, "advance_kernel's static LDS outgrew its allowance");
 
 // Copies of the weight trees' tops for one launch of advance_kernel: every node whose index is a
@@ -532,6 +538,7 @@ int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out) {
   const uint32_t nthr = cfg->threads_per_chain ? cfg->threads_per_chain : (cfg->max_observations <= 4096 ? 128 : 256);
   if (nthr < 64 || nthr > 1024 || !is_pow2(nthr))
     return fail(nullptr, MCMCGPU_ERR_ARGUMENT, "threads_per_chain must be a power of two in [64, 1024]");
+  if (cfg->serial_program > 2) return fail(nullptr, MCMCGPU_ERR_ARGUMENT, "serial_program must be 0, 1 or 2");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(nullptr, MCMCGPU_ERR_HIP, "no HIP device available (this library has no CPU path)");
@@ -1007,12 +1014,14 @@ int mcmcgpu_advance(mcmcgpu_handle h, uint32_t upto, uint32_t steps_per_timestep
   // state edges the chains have by the end of this launch: tree nodes 0 .. upto - 1
   const TreeTops tops = plan_tree_tops(h, std::max(upto, edges_grown(h)));
   const size_t dyn_lds = (size_t(tops.sw_n) + tops.fw_n) * sizeof(double);
-  auto* const kernel = h->cfg.range_bearing ? advance_kernel<true> : advance_kernel<false>;  // one per observation model
-  if (dyn_lds > h->advance_lds_allowed) {
+  // one kernel per observation model; few chains take the variant with the serial program compiled in
+  const bool solo = h->nthreads <= 256 &&  // that variant is built for at most 256 lanes
+                    (h->cfg.serial_program == 2 || (h->cfg.serial_program == 0 && h->chains <= kSoloMaxChains));
+  auto* const kernel = h->cfg.range_bearing ? (solo ? advance_kernel<true, true> : advance_kernel<true, false>)
+                                            : (solo ? advance_kernel<false, true> : advance_kernel<false, false>);
+  if (dyn_lds > 48 * 1024 && h->advance_lds_raised.insert(reinterpret_cast<const void*>(kernel)).second)
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    int(kLdsPerCu - kAdvanceStaticLds)));
-    h->advance_lds_allowed = kLdsPerCu - kAdvanceStaticLds;
-  }
   EventPair ev;
   if (int rc = begin_timed(h, &ev)) return rc;
   hipLaunchKernelGGL(kernel, dim3(h->chains), dim3(h->nthreads), dyn_lds, h->stream, h->d, h->next_timestep,
@@ -1643,7 +1652,7 @@ int mcmcgpu_comm_init_all(mcmcgpu_handle* handles, int n, uint32_t slots_per_ran
   const ncclResult_t made = rccl().CommInitAll(comms.data(), n, devices.data());
   if (made != ncclSuccess) {  // no communicators: every handle back to the buffers of a handle on its own
     for (int i = 0; i < n; ++i) {
-      hipSetDevice(handles[i]->cfg.device);
+      (void)hipSetDevice(handles[i]->cfg.device);
       ensure_exchange_buffers(handles[i], 1, handles[i]->cfg.max_chains);
     }
     return fail(h0, MCMCGPU_ERR_HIP, std::string("ncclCommInitAll: ") + rccl().GetErrorString(made));
@@ -1950,6 +1959,64 @@ int mcmcgpu_selftest_scan(int32_t device, uint32_t n, int32_t p, const int32_t* 
   if (e == hipSuccess) e = hipMemcpy(out_b, ob, sizeof(int32_t) * n, hipMemcpyDeviceToHost);
   (void)hipFree(buf);
   if (e != hipSuccess) return fail(nullptr, MCMCGPU_ERR_HIP, std::string("scan self-test: ") + hipGetErrorString(e));
+  return 0;
+}
+
+int mcmcgpu_selftest_wave(int32_t device, uint32_t seed, uint32_t n, const uint8_t* kinds, double* out_serial, double* out_wave,
+                          uint32_t tree_n, const double* weights, uint32_t n_search, const double* search_u,
+                          uint32_t* index_serial, uint32_t* index_wave) {
+  if (!kinds || !out_serial || !out_wave || !weights || !search_u || !index_serial || !index_wave || n == 0 || tree_n == 0 ||
+      n_search == 0)
+    return fail(nullptr, MCMCGPU_ERR_ARGUMENT, "bad argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+    return fail(nullptr, MCMCGPU_ERR_HIP, "no such HIP device");
+  mcmcgpu_handle h = nullptr;
+  HIP_TRY(h, hipSetDevice(device));
+  // one allocation: kinds | draws (serial, wave) | weights, nodes | search uniforms | indices (serial, wave)
+  const size_t nk = (size_t(n) + 7) / 8 * 8;
+  const size_t bytes = nk + sizeof(double) * (2 * size_t(n) + 2 * size_t(tree_n) + n_search) + sizeof(uint32_t) * 2 * size_t(n_search);
+  unsigned char* buf = nullptr;
+  HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&buf), bytes));
+  uint8_t* d_kinds = buf;
+  double* d_serial = reinterpret_cast<double*>(buf + nk);
+  double* d_wave = d_serial + n;
+  double* d_weights = d_wave + n;
+  double* d_nodes = d_weights + tree_n;
+  double* d_u = d_nodes + tree_n;
+  uint32_t* d_is = reinterpret_cast<uint32_t*>(d_u + n_search);
+  uint32_t* d_iw = d_is + n_search;
+  // the tree in the reference's layout (bitree<double>::push_back, src/utility/bitree.hpp:182-184), built here
+  std::vector<double> nodes(tree_n);
+  for (uint32_t i = 0; i < tree_n; ++i) wt::push_back(wt::Plain{nodes.data()}, i, weights[i]);
+  hipError_t e = hipMemcpy(d_kinds, kinds, n, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_nodes, nodes.data(), sizeof(double) * tree_n, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_u, search_u, sizeof(double) * n_search, hipMemcpyHostToDevice);
+  const char* stage = "copies";
+  auto ran = [&](const char* what) {  // every kernel is waited for, so that a failure names it
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess && stage[0] == 'c') stage = what;
+  };
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(serial_draws_selftest_kernel, dim3(1), dim3(64), 0, nullptr, seed, n, d_kinds, d_serial);
+    ran("one-lane draws");
+  }
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(wave_draws_selftest_kernel, dim3(1), dim3(64), 0, nullptr, seed, n, d_kinds, d_wave);
+    ran("64-lane draws");
+  }
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(search_selftest_kernel, dim3(1), dim3(64), 0, nullptr, tree_n, d_nodes, n_search, d_u, d_is, d_iw);
+    ran("descents");
+  }
+  if (e == hipSuccess) e = hipMemcpy(out_serial, d_serial, sizeof(double) * n, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(out_wave, d_wave, sizeof(double) * n, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(index_serial, d_is, sizeof(uint32_t) * n_search, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(index_wave, d_iw, sizeof(uint32_t) * n_search, hipMemcpyDeviceToHost);
+  (void)hipFree(buf);
+  if (e != hipSuccess)
+    return fail(nullptr, MCMCGPU_ERR_HIP, std::string("wavefront self-test (") + stage + "): " + hipGetErrorString(e));
   return 0;
 }
 

@@ -18,6 +18,7 @@ RECORD = np.dtype(
         ("proposed", np.float64, (3,)),
         ("log_ratio", np.float64),
         ("log_likelihood", np.float64),
+        ("term_scale", np.float64),  # sum of |log density| over the terms of log_ratio
     ],
     align=True,
 )
@@ -38,6 +39,7 @@ def lib():
         L.ora_chain_full_log_likelihood.restype = ctypes.c_double
         L.ora_chain_eval.restype = ctypes.c_double
         L.ora_chain_units.restype = ctypes.c_uint64
+        L.ora_chain_min_accept_margin.restype = ctypes.c_double
         L.ora_world_update_all.restype = ctypes.c_uint64
         L.ora_chain_trace_size.restype = ctypes.c_uint32
         for name in ("ora_world_dims", "ora_world_get_input", "ora_chain_trace_enable", "ora_chain_trace_get",
@@ -208,6 +210,10 @@ class World:
 
     def units(self, chain):
         return self.L.ora_chain_units(self.w, chain)
+
+    def min_accept_margin(self, chain):
+        """Smallest relative distance of an accept test's two sides over the chain's steps so far."""
+        return self.L.ora_chain_min_accept_margin(self.w, chain)
 
     def state(self, chain):
         T, F = ctypes.c_uint32(), ctypes.c_uint32()

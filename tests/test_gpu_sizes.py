@@ -8,7 +8,7 @@ import torch
 
 import oracle_lib
 from slam_amd import capi, synthetic
-from test_gpu_parity import REL, assert_close, compare_traces
+from test_gpu_parity import REL, assert_close, compare_traces, log_ratio_errors
 
 pytestmark = pytest.mark.gpu
 
@@ -16,7 +16,8 @@ torch.cuda.is_available()  # torch's HIP runtime first (the summaries buffer bel
 
 
 def test_million_pose_ladder_in_split_mode():
-    """1 000 000 poses, 10 000 000 readings, one ladder of 8 replicas, mcmcgpu_run_split with the DEFAULT
+    """1 000 000 poses, 10 000 000 readings, one ladder of 64 replicas (the ladder bench.py --workload tempering
+    runs), mcmcgpu_run_split with the DEFAULT
     threshold for the many-workgroup pose-table update (split_commit_kernel runs from 200 000 poses on), then
     replica exchanges.  The beta = 1 chain and the hottest chain step for step against the oracle; incremental
     against from-scratch log likelihood and against a rebuild of the pose tables on all chains (the
@@ -24,7 +25,7 @@ def test_million_pose_ladder_in_split_mode():
     p = synthetic.make_problem(T=1_000_000, n_landmarks=1000, k_nearest=10, seed=12345, max_tries=2)
     T, F, N = p["T"], p["F"], p["N"]
     assert (T, N) == (1_000_000, 10_000_000)
-    R, steps, slices = 8, 30, 256
+    R, steps, slices = 64, 12, 256
     betas = np.geomspace(1.0, 1e-5, R)  # the hot end accepts most state edges: the pose-table kernel gets work
     seeds = capi.seed_sequence(4711, R)
     g = capi.McmcGpu(R, T, F, N, trace_capacity=2 * steps, max_split_slices=slices)  # split_commit_min_poses = default
@@ -55,7 +56,8 @@ def test_million_pose_ladder_in_split_mode():
         w.load_state(k, p["true_rel"], np.arange(F), p["landmarks"])
         w.set_beta(k, betas[c])
         assert w.update(k, steps) >= 0
-        compare_traces(traces[c], w.trace(k), abs(w.log_likelihood(k)))
+        print("chain", c, "log-ratio differences (absolute, in units of the terms' sum):", log_ratio_errors(traces[c], w.trace(k)))
+        compare_traces(traces[c], w.trace(k))
         assert units[c] == w.units(k), "evaluated-observation counts differ"
         if c == mover:
             assert_close(before, w.state(k)["cum"], REL, "cumulative poses vs the oracle's tree")
@@ -65,11 +67,11 @@ def test_million_pose_ladder_in_split_mode():
     beta_now, slot, _, attempts, swaps = g.ladders()
     assert attempts == R // 2 + (R - 1) // 2 and sorted(beta_now) == sorted(betas)
     assert np.array_equal(np.sort(slot), np.arange(R))
-    g.run_split(10, slices)
+    g.run_split(6, slices)
     g.sync()
     assert_close(g.log_likelihood(), g.full_log_likelihood(), REL, "incremental vs from-scratch after the exchange")
     upd, _, _ = g.counters()
-    assert np.all(upd == steps + 10)
+    assert np.all(upd == steps + 6)
 
 
 def test_benchmark_launch_shape_1024_chains():

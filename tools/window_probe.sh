@@ -3,7 +3,8 @@
 # with every proposal rejected (so the chains stay at their starting state and the three runs do
 # the same work): as it is; with every pose gather confined to a 16 KB window of the chain's table;
 # with every record load confined to a 48 KB window (which confines the pose gathers to those
-# records' timesteps as well).  Results are wrong by construction; rates and FETCH_SIZE are what
+# records' timesteps as well); and with 8-byte records whose timestep is arithmetic on the segment
+# (the bound on a stream over runs of consecutive timesteps: no dependent load, 4 bytes fewer).  Results are wrong by construction; rates and FETCH_SIZE are what
 # is read off.
 #   tools/window_probe.sh build      here (hipcc cross-compiles): tools/diag/libmcmcgpu_win_*.so
 #   tools/window_probe.sh            on the GPU box, from the repository root -> gpurun_out/window_probe/
@@ -11,9 +12,9 @@ set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 if [ "$1" = build ]; then
   mkdir -p "$R/tools/diag"
-  for v in NONE POSE RECORD; do
+  for v in NONE POSE RECORD RUN; do
     ${HIPCC:-/opt/rocm/bin/hipcc} -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared -std=c++17 \
-      -DMG_DIAG_${v}_WINDOW -DMG_DIAG_REJECT_ALL -Wall -Wno-unused-function \
+      -DMG_DIAG_${v}_WINDOW -DMG_DIAG_${v}_RECORDS -DMG_DIAG_REJECT_ALL -Wall -Wno-unused-function \
       -o "$R/tools/diag/libmcmcgpu_win_$v.so" "$R/slam_amd/csrc/mcmcgpu.hip"
   done
   exit 0
@@ -23,7 +24,7 @@ mkdir -p "$O"
 cd /tmp
 export TMPDIR=/tmp
 ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-plaza --no-live-traffic"
-for v in NONE POSE RECORD; do
+for v in NONE POSE RECORD RUN; do
   export MCMCGPU_LIB=$R/tools/diag/libmcmcgpu_win_$v.so
   timeout -k 10 120 python3 "$R/bench.py" $ARGS > "$O/bench_$v.json" 2> "$O/bench_$v.err"
   timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/fetch_$v" -- \
@@ -34,9 +35,10 @@ python3 - <<'PY' | tee gpurun_out/window_probe/summary.txt
 import csv, datetime, glob, json, os, sys
 sys.path.insert(0, os.getcwd())
 import bench as bench_module
-names = {"NONE": "as it is", "POSE": "pose gathers in a 16 KB window", "RECORD": "record loads in a 48 KB window"}
+names = {"NONE": "as it is", "POSE": "pose gathers in a 16 KB window", "RECORD": "record loads in a 48 KB window",
+         "RUN": "8-byte records, timestep from the segment"}
 per_unit, rate, cfg = {}, {}, None
-for v in ("NONE", "POSE", "RECORD"):
+for v in ("NONE", "POSE", "RECORD", "RUN"):
     b = json.loads([ln for ln in open(f"gpurun_out/window_probe/bench_{v}.json") if ln.startswith("{")][-1])
     cfg = b["config"]
     units = b["value"] * b["ms_per_step"] / 1e3
