@@ -43,7 +43,7 @@ typedef struct mcmcgpu_config {
   uint32_t max_timesteps;     /* capacity for controls (state edges) */
   uint32_t max_features;      /* capacity for landmarks */
   uint32_t max_observations;  /* capacity for range readings */
-  uint32_t threads_per_chain; /* workgroup size; 0 -> 256 (128 when max_observations <= 4096); power of two in [64, 1024] */
+  uint32_t threads_per_chain; /* workgroup size; 0 -> 256 (128 when max_observations <= 4096 and max_chains > 256); power of two in [64, 1024] */
   /* Order of the two draws inside a landmark proposal.  The reference leaves it
    * unsequenced (src/planar_robot/range_bearing_model.hpp:155-159): 1 = uniform
    * then normal (what g++ emits), 0 = normal then uniform (clang). */

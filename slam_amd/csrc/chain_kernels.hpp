@@ -1149,11 +1149,15 @@ MG_DEV void refresh_totals(const Dev& d, uint32_t c, Shared& S) {
 
 // Selection and proposal of one update (mcmc_slam.hpp:339-368, :375-382).
 // Returns false when nothing can be updated (both weight totals zero, :345).
-// Index draw on a weight tree: the serial descent, or the wavefront's when all 64 lanes run this code.
+// Index draw on a weight tree.  The wavefront form of the descent (wt::search_wave: six levels per
+// memory latency) is bit-identical but not faster where it could be used: a lone wavefront issues a
+// dependent instruction about every ten cycles, and what six levels save in LDS latency they spend
+// on the walk through the probed nodes (Plaza1, 14 levels: 5 900 cycles against the serial 4 600).
+constexpr bool kWaveDescent = false;
 template <class R>
 MG_DEV uint32_t draw_index(const wt::Cached& tree, uint32_t n, double value) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  if (R::kWave) return wt::search_wave(tree, n, value);
+  if (R::kWave && kWaveDescent) return wt::search_wave(tree, n, value);
 #endif
   return wt::search(tree, n, value);
 }
@@ -1570,8 +1574,8 @@ MG_DEV void step_body(DevArgs dp, SharedLds sp, uint32_t c, double r) {
 
 MG_PIECE void piece_step(DevArgs dp, SharedLds sp, uint32_t c, double r) { step_body<false>(dp, sp, c, r); }
 
-MG_PIECE void piece_commit(DevArgs dp, SharedLds sp, uint32_t c, uint32_t idx, double qx, double qy, double qth,
-                           uint32_t Tcur) {
+MG_DEV void commit_body(DevArgs dp, SharedLds sp, uint32_t c, uint32_t idx, double qx, double qy, double qth,
+                        uint32_t Tcur) {
   const Dev& d = *(const Dev*)dp;
   Shared& S = *(Shared*)sp;
   commit_state_edge(d, c, idx, Pose{qx, qy, qth}, Tcur, S.nf);
@@ -1582,6 +1586,10 @@ MG_PIECE void piece_commit(DevArgs dp, SharedLds sp, uint32_t c, uint32_t idx, d
     d.relth[ri] = qth;
     S.n_moved += Tcur - idx;  // poses idx+1 .. Tcur rewritten
   }
+}
+MG_PIECE void piece_commit(DevArgs dp, SharedLds sp, uint32_t c, uint32_t idx, double qx, double qy, double qth,
+                           uint32_t Tcur) {
+  commit_body(dp, sp, c, idx, qx, qy, qth, Tcur);
 }
 
 // grid = chains, block = threads_per_chain.  first_tn = the next timestep the
@@ -1644,7 +1652,10 @@ __global__ void __launch_bounds__(SOLO ? 256 : 1024) advance_kernel(Dev d, uint3
     const double qx = S.q[0], qy = S.q[1], qth = S.q[2];
     const uint32_t Tcur = S.Tcur, nf = S.nf;
     if (op == OP_COMMIT) {  // the state edge just accepted: all lanes move the pose table, then lane 0 goes on
-      piece_commit(dp, sp, c, idx, qx, qy, qth, Tcur);
+      if (SOLO)
+        commit_body(dp, sp, c, idx, qx, qy, qth, Tcur);
+      else
+        piece_commit(dp, sp, c, idx, qx, qy, qth, Tcur);
       __syncthreads();
       MG_STAMP(tg1);
       MG_PHASE_ADD(S, 5, td1, tg1);

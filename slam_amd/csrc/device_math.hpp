@@ -311,67 +311,62 @@ MG_DEV double readlane_f64(double v, int lane) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
 // search() for a whole wavefront whose 64 lanes all hold the same arguments (and get the same
-// result): the descent's comparisons are sequential -- each decides which node is probed next --
-// but there are only two outcomes each, so lane L plays the next six comparisons ASSUMING the
-// outcomes that the bits of L spell.  Which nodes a lane probes then depends on its lane number
-// alone: all six loads go out together, and the additions and comparisons that follow are the
-// serial code's, operation for operation, on the one lane whose assumptions all hold.  Six levels
-// cost one memory latency instead of six.
+// result).  The descent's comparisons are sequential, but the nodes the next six of them can
+// probe form a binary tree of 63: lane L loads the node at heap position L of that tree (root 1,
+// the node after a "left" at 2L, after a "right" at 2L + 1), all loads go out together, and the
+// comparisons then walk that tree with v_readlane -- the serial code's additions and comparisons,
+// operation for operation, with one memory latency per six levels.  Once the range [lo, hi) is a
+// power of two wide and aligned to its width (after the first "left", and so almost always from
+// the second round on) the node under a heap position is arithmetic: lo + (hi - lo) (2p + 1) /
+// 2^(d+1) for depth d and path p; before that every lane replays its path with child_containing.
 template <class N>
 MG_DEV uint32_t search_wave(const N& node, uint32_t n, double value) {
   if (n == 0 || value < node.ld(0)) return 0;
   const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t d = 31u - uint32_t(__clz(int(lane | 1u)));  // depth of this lane's heap position (lane 0: unused)
+  const uint32_t path = lane & ((1u << d) - 1u);             // its decisions, the first in the top bit
+  constexpr uint32_t kNone = 0xFFFFFFFFu;
   uint32_t lo = 0, hi = n;
   double origin = node.ld(0);
-  constexpr int kLevels = 6;
-  // (a 32-bit index has at most 32 levels: the bound only keeps a wavefront whose lanes disagree --
-  // which the callers rule out -- from spinning)
-  for (int round = 0; round < 6 && lo + 1 < hi; ++round) {
-    uint32_t mids[kLevels];
-    double at[kLevels];
-    {
+  // (a 32-bit index has at most 32 levels: the bound only keeps corrupted arguments from spinning)
+  for (int round = 0; round < 7 && lo + 1 < hi; ++round) {
+    uint32_t mine = kNone;
+    const uint32_t w = hi - lo;
+    if ((w & (w - 1u)) == 0 && (lo & (w - 1u)) == 0) {  // same in all lanes
+      const uint32_t step = w >> (d + 1u);
+      if (step) mine = lo + step * (2u * path + 1u);
+    } else {
       uint32_t l = lo, h = hi;
 #pragma unroll
-      for (int k = 0; k < kLevels; ++k) {
-        mids[k] = 0xFFFFFFFFu;
-        at[k] = 0.0;
-        if (l + 1 < h) {
-          const uint32_t mid = child_containing(l, h - 1);
-          mids[k] = mid;
-          at[k] = node.ld(mid);
-          if ((lane >> k) & 1u)
-            l = mid;
-          else
-            h = mid;
+      for (uint32_t k = 0; k < 6; ++k) {
+        const bool open = l + 1 < h;
+        const uint32_t last = h - 1;
+        // child_containing(l, last); "| 1" keeps the count defined when the descent has ended (l == last)
+        const uint32_t mid = last & ~(0x7FFFFFFFu >> __clz(int((l ^ last) | 1u)));
+        if (k == d) mine = open ? mid : kNone;
+        if (k < d) {
+          const bool right = (path >> (d - 1u - k)) & 1u;
+          l = (open && right) ? mid : l;
+          h = (open && !right) ? mid : h;
+          if (!open) h = l + 1;  // the path has left the tree: nothing below it
         }
       }
     }
-    uint32_t l = lo, h = hi;
-    double o = origin;
-    bool consistent = true;
-#pragma unroll
-    for (int k = 0; k < kLevels; ++k) {
-      const bool assumed = (lane >> k) & 1u;
-      if (mids[k] != 0xFFFFFFFFu) {
-        const double s = o + at[k];
-        const bool right = !(value < s);  // the serial code's `else` branch: lo = mid, origin += at_mid
-        consistent = consistent && (right == assumed);
-        if (assumed) {
-          l = mids[k];
-          o = s;
-        } else {
-          h = mids[k];
-        }
+    const double val = node.ld(mine != kNone ? mine : 0u);
+    uint32_t at = 1;
+    for (int k = 0; k < 6; ++k) {
+      const uint32_t mid = uint32_t(__builtin_amdgcn_readlane(int(mine), int(at)));
+      if (mid == kNone) break;  // the descent has ended
+      const double s = origin + readlane_f64(val, int(at));
+      const bool right = __builtin_amdgcn_readfirstlane(int(!(value < s))) != 0;  // the serial code's `else` branch
+      if (right) {
+        lo = mid;
+        origin = s;
       } else {
-        consistent = consistent && !assumed;  // the descent has ended: one lane (all further bits 0) carries it
+        hi = mid;
       }
+      at = 2u * at + (right ? 1u : 0u);
     }
-    const unsigned long long mask = __ballot(consistent);
-    if (mask == 0) return n;  // cannot happen for finite weights; the caller treats n as "draw again"
-    const int src = __ffsll((long long)mask) - 1;  // exactly one lane
-    lo = uint32_t(__builtin_amdgcn_readlane(int(l), src));
-    hi = uint32_t(__builtin_amdgcn_readlane(int(h), src));
-    origin = readlane_f64(o, src);
   }
   return hi;
 }

@@ -533,9 +533,12 @@ const char* mcmcgpu_last_error(mcmcgpu_handle h) { return h ? h->error.c_str() :
 int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out) {
   if (!cfg || !out) return fail(nullptr, MCMCGPU_ERR_ARGUMENT, "null argument");
   if (cfg->max_chains == 0) return fail(nullptr, MCMCGPU_ERR_ARGUMENT, "max_chains must be positive");
-  // default width: 256 lanes; data with at most 16 readings per lane of such a workgroup (Plaza has
-  // 3 500 in all) keeps 128 busier and pays less per barrier
-  const uint32_t nthr = cfg->threads_per_chain ? cfg->threads_per_chain : (cfg->max_observations <= 4096 ? 128 : 256);
+  // default width: 256 lanes; many chains on data with at most 16 readings per lane of such a workgroup
+  // (Plaza has 3 500 in all) keep 128 busier and pay less per barrier -- but not the few chains whose
+  // serial part is compiled in (Plaza1, one chain: 28 200 cycles per update with 256 lanes, 29 500 with 128)
+  const uint32_t nthr = cfg->threads_per_chain
+                            ? cfg->threads_per_chain
+                            : (cfg->max_observations <= 4096 && cfg->max_chains > kSoloMaxChains ? 128 : 256);
   if (nthr < 64 || nthr > 1024 || !is_pow2(nthr))
     return fail(nullptr, MCMCGPU_ERR_ARGUMENT, "threads_per_chain must be a power of two in [64, 1024]");
   if (cfg->serial_program > 2) return fail(nullptr, MCMCGPU_ERR_ARGUMENT, "serial_program must be 0, 1 or 2");

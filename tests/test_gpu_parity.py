@@ -1023,3 +1023,33 @@ def test_wavefront_forms_of_generator_and_descent_equal_the_serial_ones(seed):
         assert np.array_equal(ds, dw), f"draws differ first at {np.nonzero(ds != dw)[0][:5]}"
         assert np.array_equal(i_s, i_w), f"tree of {tree_n}: indices differ at {np.nonzero(i_s != i_w)[0][:5]}"
         assert np.all(i_s <= tree_n)
+
+
+def test_tree_tops_at_full_capacity_and_many_narrow_workgroups():
+    """The LDS copies of the weight trees' tops at the edges of their planning.  (a) 1024 chains whose capacity
+    equals the data (max_timesteps = T = 4096, a multiple of the copy's stride): the copy of every second node
+    must end at the last valid node, not one stride further -- in the last chain that would be past the
+    allocation.  (b) 2304 chains of 64 lanes: nine workgroups share a CU and the static block is all the LDS
+    each gets; the launch must still run, without copies.  First and last chain step for step against the oracle."""
+    for chains, lanes, T, steps in ((1024, 0, 4096, 40), (2304, 64, 96, 60)):
+        p = synthetic.make_problem(T=T, n_landmarks=24, k_nearest=3, seed=29, lap_steps=300, wobble_period=700,
+                                   range_stddev=1.5, landmark_spread=8.0)
+        assert p["T"] == T
+        seeds = capi.seed_sequence(4242, chains)
+        g = capi.McmcGpu(chains, p["T"], p["F"], p["N"], trace_capacity=steps, threads_per_chain=lanes)
+        g.upload_problem(p["ctrl_mean"], p["ctrl_std"], p["obs_t"], p["obs_f"], p["obs_mean"], p["obs_std"], p["F"])
+        g.init_chains(seeds)
+        g.load_state(p["true_rel"], p["landmarks"])
+        g.run(steps)
+        g.sync()
+        ll = g.log_likelihood()
+        w = oracle_lib.World()
+        w.set_input(p["ctrl_mean"], p["ctrl_std"], p["obs_t"], p["obs_f"], p["obs_mean"], p["obs_std"])
+        w.replay(p["T"])
+        for c in (0, chains - 1):
+            k = w.add_detached_chain(int(seeds[c]), trace=True)
+            w.load_state(k, p["true_rel"], np.arange(p["F"]), p["landmarks"])
+            assert w.update(k, steps) >= 0
+            compare_traces(g.trace(c), w.trace(k))
+            assert_close(ll[c], w.log_likelihood(k), REL, f"{chains} chains: chain {c} log likelihood")
+        g.close()
