@@ -112,6 +112,10 @@ struct Dev {
   // lanes on neighbouring addresses instead of one scattered table line per landmark; with it the
   // cosine and sine of its angle (taken anew whenever the angle changes)
   double *fpx, *fpy, *fpth, *fpc, *fps;
+  // [C][Fcap] the parent READING as a distribution (measured range and its sigma; bearing and its sigma,
+  // null on a range-only handle): a copy of what foff[f] + fpar indexes, so that a landmark proposal
+  // finds its distribution in one load instead of three dependent ones
+  double *fpmu, *fpsd, *fpbmu, *fpbsd;
   uint32_t* flast;              // [C][Fcap]   timestep of the latest reading seen
   uint32_t* nf;                 // [C]         landmarks known
   double* ll;                   // [C]         chain log likelihood
@@ -1063,6 +1067,25 @@ MG_DEV Reading load_reading(const Dev& d, uint32_t o) {
   return m;
 }
 
+// The parent reading of landmark entry fi, from its copy beside the landmark / the copy taken anew.
+MG_DEV Reading parent_reading(const Dev& d, size_t fi) {
+  Reading m;
+  m.mu = d.fpmu[fi];
+  m.sd = d.fpsd[fi];
+  m.bearing = d.obear != nullptr;
+  m.bmu = m.bearing ? d.fpbmu[fi] : 0.0;
+  m.bsd = m.bearing ? d.fpbsd[fi] : 1.0;
+  return m;
+}
+MG_DEV void keep_parent_reading(const Dev& d, size_t fi, const Reading& m) {
+  d.fpmu[fi] = m.mu;
+  d.fpsd[fi] = m.sd;
+  if (m.bearing) {
+    d.fpbmu[fi] = m.bmu;
+    d.fpbsd[fi] = m.bsd;
+  }
+}
+
 // proposal_dist::operator() of the reading's model.  Range only
 // (range_bearing_model.hpp:155-159): polar(N(mu, sigma), U 2 pi), draw order by flag.  Range and
 // bearing (:84-86): inv_observe of two normals drawn in index order (random.hpp:94-100).
@@ -1210,7 +1233,7 @@ MG_DEV bool driver_begin_update(const Dev& d, uint32_t c, Shared& S, R& rng) {
       return false;
     }
     const size_t fi = size_t(c) * d.Fcap + f;
-    const Reading m = load_reading(d, d.foff[f] + d.fpar[fi]);
+    const Reading m = parent_reading(d, fi);
     const Vec2 q = propose_landmark(d, rng, m);
     S.new_pll = reading_proposal_log_pdf(m, q);
     S.old_pll = reading_proposal_log_pdf(m, Vec2{d.fex[fi], d.fey[fi]});
@@ -1236,26 +1259,41 @@ MG_DEV bool driver_finish_update(const Dev& d, uint32_t c, Shared& S, R& rng, do
   const double proposal_log_ratio = S.new_pll - S.old_pll;
   // state edge: the control term of :436-438 is the same pair of numbers
   const double log_ratio = is_state ? (S.new_pll - S.old_pll) + obs_ratio : obs_ratio;
-  double new_log_weight;
-  const double new_weight = edge_weight_from_log_pdf(S.new_pll, dim, &new_log_weight);
+  // the three exponentials of the step (:389, :397, :408) have their arguments ready together: a
+  // wavefront takes one each in three lanes, one lane takes them one after the other; same values
+  const double new_log_weight = log(dim) - S.new_pll / dim;  // edge_log_weight, :160-162
+  const double old_log_weight = log(dim) - S.old_pll / dim;
   double normaliser = 1.0;
   // a tempered replica targets controls x readings^beta: the readings' part of the ratio is
   // weighed by the inverse temperature; with beta = 1 this is log_ratio bit for bit
   const double tempered = is_state ? (S.new_pll - S.old_pll) + S.beta * obs_ratio : S.beta * obs_ratio;
   double accept_log_ratio = tempered - proposal_log_ratio;
+  if (S.use_weight) accept_log_ratio += new_log_weight - old_log_weight;
+  double new_weight, old_weight, accept_bar;
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (R::kWave) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const double e = exp(lane == 1 ? old_log_weight : lane == 2 ? accept_log_ratio : new_log_weight);
+    new_weight = wt::readlane_f64(e, 0);
+    old_weight = wt::readlane_f64(e, 1);
+    accept_bar = wt::readlane_f64(e, 2);
+  } else
+#endif
+  {
+    new_weight = exp(new_log_weight);
+    old_weight = S.use_weight ? exp(old_log_weight) : 0.0;
+    accept_bar = exp(accept_log_ratio);
+  }
   const wt::Cached sw = state_tree(d, c, S), fw = landmark_tree(d, c, S);
   if (S.use_weight) {
-    double old_log_weight;
-    const double old_weight = edge_weight_from_log_pdf(S.old_pll, dim, &old_log_weight);
     refresh_totals(d, c, S);
     const double weight_sum = S.Ws + S.Wf;
     normaliser += (new_weight - old_weight) / weight_sum;
-    accept_log_ratio += new_log_weight - old_log_weight;
   }
 #ifdef MG_DIAG_REJECT_ALL  // diagnostic builds: the chains stay where they are whatever the streams computed
-  const bool accept = (normaliser * rng.uniform() < exp(accept_log_ratio)) && false;
+  const bool accept = (normaliser * rng.uniform() < accept_bar) && false;
 #else
-  const bool accept = normaliser * rng.uniform() < exp(accept_log_ratio);
+  const bool accept = normaliser * rng.uniform() < accept_bar;
 #endif
   if (accept) {
     if (is_state) {
@@ -1300,6 +1338,7 @@ MG_DEV bool driver_arrival(const Dev& d, uint32_t c, Shared& S, R& rng, uint32_t
     d.fex[fi] = est.x;
     d.fey[fi] = est.y;
     d.fpar[fi] = 0;
+    keep_parent_reading(d, fi, m);
     d.fcnt[fi] = 1;
     d.fpt[fi] = t;
     keep_parent_pose(d, c, fi, t);
@@ -1316,9 +1355,10 @@ MG_DEV bool driver_arrival(const Dev& d, uint32_t c, Shared& S, R& rng, uint32_t
   const Vec2 w = act(parent_frame(d, fi), Vec2{d.fex[fi], d.fey[fi]});
   const Vec2 est = act_inverse(world_pose(d, c, t), w);
   S.ll += reading_log_pdf(m, est);
-  const double par_mu = d.orec[d.foff[f] + d.fpar[fi]].mu;
+  const double par_mu = d.fpmu[fi];
   if (fabs(mu) < fabs(par_mu)) {  // more_accurate_than, range_bearing_model.hpp:141-143
     d.fpar[fi] = rel;
+    keep_parent_reading(d, fi, m);
     d.fpt[fi] = t;
     keep_parent_pose(d, c, fi, t);
     d.fex[fi] = est.x;
@@ -1549,30 +1589,39 @@ MG_DEV void step_with(const Dev& d, uint32_t c, Shared& S, R& rng, double r) {
 // WAVE: the body is run by all 64 lanes of a wavefront on the same data (every lane computes and
 // stores the same values), which lets the generator's window and the weight trees' descents use
 // the lanes (WaveRng, wt::search_wave); otherwise by one lane.  Same results either way.
-template <bool WAVE>
+// The body run by ONE lane (the called piece below).
 MG_DEV void step_body(DevArgs dp, SharedLds sp, uint32_t c, double r) {
   const Dev& d = *(const Dev*)dp;
   Shared& S = *(Shared*)sp;
 #ifdef MG_PHASE_TIMING
   const long long t_in = clock64();
 #endif
-#if defined(__HIP_DEVICE_COMPILE__)
-  if (WAVE) {
-    WaveRng rng(S.rng);
-    step_with(d, c, S, rng, r);
-    rng.flush();
-  } else
-#endif
-  {
-    SerialRng rng{S.rng};
-    step_with(d, c, S, rng, r);
-  }
+  SerialRng rng{S.rng};
+  step_with(d, c, S, rng, r);
 #ifdef MG_PHASE_TIMING
   S.phase[7] += clock64() - t_in;  // slot 7: first to last instruction of the body (the call is the rest)
 #endif
 }
 
-MG_PIECE void piece_step(DevArgs dp, SharedLds sp, uint32_t c, double r) { step_body<false>(dp, sp, c, r); }
+#if defined(__HIP_DEVICE_COMPILE__)
+// The body run by all 64 lanes of a wavefront on the same data (every lane computes and stores the
+// same values), which lets the generator hand out its words from a window held in the lanes
+// (WaveRng).  The window object lives in the kernel's registers from launch to end: one fetch of
+// 64 words serves several updates.  Same results as the one-lane body.
+MG_DEV void step_body_wave(DevArgs dp, SharedLds sp, uint32_t c, double r, WaveRng& rng) {
+  const Dev& d = *(const Dev*)dp;
+  Shared& S = *(Shared*)sp;
+#ifdef MG_PHASE_TIMING
+  const long long t_in = clock64();
+#endif
+  step_with(d, c, S, rng, r);
+#ifdef MG_PHASE_TIMING
+  S.phase[7] += clock64() - t_in;
+#endif
+}
+#endif
+
+MG_PIECE void piece_step(DevArgs dp, SharedLds sp, uint32_t c, double r) { step_body(dp, sp, c, r); }
 
 MG_DEV void commit_body(DevArgs dp, SharedLds sp, uint32_t c, uint32_t idx, double qx, double qy, double qth,
                         uint32_t Tcur) {
@@ -1636,10 +1685,15 @@ __global__ void __launch_bounds__(SOLO ? 256 : 1024) advance_kernel(Dev d, uint3
   __syncthreads();
   MG_STAMP(tk0);
   double r = 0.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  WaveRng wave_rng(S.rng);  // used by the first wavefront of the SOLO variant only
+#endif
   for (;;) {
     MG_STAMP(td0);
     if (SOLO) {
-      if (threadIdx.x < 64) step_body<true>(dp, sp, c, r);  // the first wavefront, all lanes on the same data
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (threadIdx.x < 64) step_body_wave(dp, sp, c, r, wave_rng);  // the first wavefront, all lanes on the same data
+#endif
     } else {
       if (threadIdx.x == 0) piece_step(dp, sp, c, r);
     }
@@ -1669,6 +1723,9 @@ __global__ void __launch_bounds__(SOLO ? 256 : 1024) advance_kernel(Dev d, uint3
     MG_STAMP(te1);
     if (op != OP_EVAL_STATE) MG_PHASE_ADD(S, 3, td1, te1);
   }
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (SOLO && threadIdx.x < 64) wave_rng.flush();  // chain_state_store begins with a barrier
+#endif
   MG_STAMP(tk1);
   MG_PHASE_ADD(S, 6, tk0, tk1);
 #ifdef MG_PHASE_TIMING
@@ -2548,7 +2605,9 @@ __global__ void reweigh_kernel(Dev d, uint32_t first, uint32_t Tcur) {
   const uint32_t nf = d.nf[c];
   for (uint32_t f = threadIdx.x; f < nf; f += blockDim.x) {
     const size_t fi = size_t(c) * d.Fcap + f;
-    const double lp = reading_proposal_log_pdf(load_reading(d, d.foff[f] + d.fpar[fi]), Vec2{d.fex[fi], d.fey[fi]});
+    const Reading parent = load_reading(d, d.foff[f] + d.fpar[fi]);
+    keep_parent_reading(d, fi, parent);  // the landmarks' state has just been loaded: take the copy anew
+    const double lp = reading_proposal_log_pdf(parent, Vec2{d.fex[fi], d.fey[fi]});
     fw[f] = edge_weight_from_log_pdf(lp, 2.0, nullptr);
   }
   build_tree_levels(fw, nf);

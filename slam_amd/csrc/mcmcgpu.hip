@@ -629,6 +629,12 @@ int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out) {
   ALLOC(d.fpth, C * d.Fcap);
   ALLOC(d.fpc, C * d.Fcap);
   ALLOC(d.fps, C * d.Fcap);
+  ALLOC(d.fpmu, C * d.Fcap);
+  ALLOC(d.fpsd, C * d.Fcap);
+  if (cfg->range_bearing) {
+    ALLOC(d.fpbmu, C * d.Fcap);
+    ALLOC(d.fpbsd, C * d.Fcap);
+  }
   ALLOC(d.flast, C * d.Fcap);
   ALLOC(d.nf, C);
   ALLOC(d.ll, C);
