@@ -260,6 +260,10 @@ struct Shared {
   uint32_t act[kActCap];
   uint32_t segpre[kMaxSeg + 1];
   uint32_t seglo[kMaxSeg];
+  // per segment, what a stream's cursor needs when it enters it, in one 8-byte read: where the segment
+  // ends in the flattened index space (segpre[k + 1]) and what turns such an index into a record
+  // position (seglo[k] - segpre[k])
+  uint2 segcur[kMaxSeg];
   double segw[kMaxSeg][4];  // old landmark (x,y), new landmark (x,y), world frame
 #ifdef MG_DIAG_RUN_RECORDS  // diagnostic builds (tools/window_probe.sh): timestep of a segment's first reading
   uint32_t segt[kMaxSeg];
@@ -354,21 +358,21 @@ MG_DEV double block_sum(double v, Shared& S) {
   return r;
 }
 
-// |(dx, dy)| to within 3 ulp (measured: 2.8e-16 relative at worst): v_rsq_f64 seed, which is good
-// to about 24 bits, plus two Goldschmidt steps with fused multiply-adds (one step leaves 4e-15).
-// The correctly rounded sqrt the compiler emits costs about twice the instructions.  Inputs are
-// lengths in metres; the 1e-280 keeps a zero distance finite (it vanishes against any squared
-// distance above 1e-264).
+// |(dx, dy)| to within 2 ulp (measured: 2.2e-16 relative at worst): v_rsq_f64 seed y = (1 + e) / sqrt(x),
+// good to about 24 bits, then ONE third-order correction: with s = x y = sqrt(x) (1 + e) and
+// r = 1/2 - (y/2) s = -e - e^2/2 the root is s (1 + r + 3/2 r^2) up to e^3 -- six instructions after the
+// seed.  (Two second-order Goldschmidt steps: seven instructions, 2.8e-16, 1.3 % slower on the whole
+// benchmark; one such step: four instructions, 4e-15, 2.2 % faster -- not taken, the stream's accuracy
+// stays at the rounding level.)  The correctly rounded sqrt the compiler emits costs about twice the
+// instructions.  Inputs are lengths in metres; the 1e-280 keeps a zero distance finite (it vanishes
+// against any squared distance above 1e-264).
 MG_DEV double range_of(double dx, double dy) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const double x = fma(dx, dx, fma(dy, dy, 1e-280));
   const double y = __builtin_amdgcn_rsq(x);
-  double s = x * y, h = 0.5 * y;
-  double r = fma(-h, s, 0.5);
-  s = fma(s, r, s);
-  h = fma(h, r, h);
-  r = fma(-h, s, 0.5);
-  return fma(s, r, s);
+  const double s = x * y, h = 0.5 * y;
+  const double r = fma(-h, s, 0.5);
+  return fma(s, r * fma(1.5, r, 1.0), s);
 #else
   return sqrt(dx * dx + dy * dy);
 #endif
@@ -431,7 +435,7 @@ struct RatioStream {
 
   MG_DEV RatioStream(const Dev& d_, uint32_t c, const Shared& S_, uint32_t nseg)
       : d(d_), S(S_), pxy(d_.pxy + size_t(c) * (d_.Tcap + 1)), total(S_.segpre[nseg]), stride(blockDim.x),
-        half_isd2(0.5 * d_.usig_inv * d_.usig_inv), seg_end(S_.segpre[1]), seg_base(S_.seglo[0]) {
+        half_isd2(0.5 * d_.usig_inv * d_.usig_inv), seg_end(S_.segcur[0].x), seg_base(S_.segcur[0].y) {
 #ifdef MG_DIAG_RUN_RECORDS
     seg_tbase = S_.segt[0];
 #endif
@@ -444,11 +448,13 @@ struct RatioStream {
       const uint32_t i = i0 + u * stride;
       if (i < total) {
         if (i >= seg_end) {
+          uint2 entry;
           do {
             ++cur;
-            seg_end = S.segpre[cur + 1];
-          } while (i >= seg_end);
-          seg_base = S.seglo[cur] - S.segpre[cur];
+            entry = S.segcur[cur];
+          } while (i >= entry.x);
+          seg_end = entry.x;
+          seg_base = entry.y;
 #ifdef MG_DIAG_RUN_RECORDS
           seg_tbase = S.segt[cur] - S.segpre[cur];
 #endif
@@ -507,8 +513,9 @@ struct RatioStream {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const double* w = S.segw[sg[u]];
-      const double ro = range_of(w[0] - p_this.p[u].x, w[1] - p_this.p[u].y);
-      const double rn = range_of(w[2] - p_this.p[u].x, w[3] - p_this.p[u].y);
+      const double wox = w[0], woy = w[1], wnx = w[2], wny = w[3];  // both positions asked for before either is used
+      const double ro = range_of(wox - p_this.p[u].x, woy - p_this.p[u].y);
+      const double rn = range_of(wnx - p_this.p[u].x, wny - p_this.p[u].y);
       const double term = (ro - rn) * fma(-2.0, mu[u], ro + rn) * k[u];
       if (i0 + u * stride < total) acc += term;
     }
@@ -789,6 +796,7 @@ MG_DEV double eval_feature_edge(const Dev& d, uint32_t c, Shared& S, uint32_t f,
     S.seglo[0] = d.foff[f];
     S.segpre[0] = 0;
     S.segpre[1] = d.fcnt[fi];
+    S.segcur[0] = make_uint2(d.fcnt[fi], d.foff[f]);
     S.segw[0][0] = wo.x;
     S.segw[0][1] = wo.y;
     S.segw[0][2] = wn.x;
@@ -931,7 +939,10 @@ MG_DEV double eval_state_edge(const Dev& d, uint32_t c, Shared& S, uint32_t t, c
   auto stream = [&](uint32_t len, uint32_t nseg) {
     uint32_t total;
     const uint32_t incl = block_scan_u32(len, S, total);
-    if (tid < nseg) S.segpre[tid + 1] = incl;
+    if (tid < nseg) {
+      S.segpre[tid + 1] = incl;
+      S.segcur[tid] = make_uint2(incl, S.seglo[tid] - (incl - len));  // this lane wrote seglo[tid] itself
+    }
     if (tid == 0) S.segpre[0] = 0;
     __syncthreads();
     units += total;

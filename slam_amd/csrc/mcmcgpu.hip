@@ -368,9 +368,9 @@ hipError_t static_scratch_on(int device, void** out) {
 
 // LDS of a CU and what advance_kernel declares statically (its Shared block, rounded up).
 #ifdef MG_DIAG_RUN_RECORDS
-constexpr size_t kLdsPerCu = 160 * 1024, kAdvanceStaticLds = 20 * 1024;  // the diagnostic build's extra table
+constexpr size_t kLdsPerCu = 160 * 1024, kAdvanceStaticLds = 22 * 1024;  // the diagnostic build's extra table
 #else
-constexpr size_t kLdsPerCu = 160 * 1024, kAdvanceStaticLds = 18 * 1024;
+constexpr size_t kLdsPerCu = 160 * 1024, kAdvanceStaticLds = 20 * 1024;
 #endif
 static_assert(sizeof(Shared) <= kAdvanceStaticLds, "advance_kernel's static LDS outgrew its allowance");
 
