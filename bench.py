@@ -253,9 +253,19 @@ def live_traffic(args, split_mode, budget_s=150.0):
                         kept.append(r)
             if args.keep_counter_csv and kept:
                 with open(f"{args.keep_counter_csv}_pmc_{counter.lower()}.csv", "w", newline="") as f:
-                    w = csv.DictWriter(f, fieldnames=reader.fieldnames)
-                    w.writeheader()
-                    w.writerows(kept)
+                    if len(kept) <= 64:
+                        w = csv.DictWriter(f, fieldnames=reader.fieldnames)
+                        w.writeheader()
+                        w.writerows(kept)
+                    else:  # split mode: thousands of dispatches -- one row per kernel
+                        per = {}
+                        for r in kept:
+                            n, v = per.get(r["Kernel_Name"], (0, 0.0))
+                            per[r["Kernel_Name"]] = (n + 1, v + float(r["Counter_Value"]))
+                        w = csv.writer(f)
+                        w.writerow(["Kernel_Name", "Counter_Name", "Dispatches", "Counter_Value_Sum", "Launches_Of_The_Run"])
+                        for name, (n, v) in sorted(per.items()):
+                            w.writerow([name, counter, n, v, launches])
             if rows == 0:
                 raise RuntimeError(f"{counter} pass saw none of the kernels {names}")
             got[counter] = total * 1024.0 / launches
@@ -309,6 +319,9 @@ def hbm_only_bracket(workload_name, updates_per_step, units_per_launch, traffic)
             rec = json.load(f)
         if rec["workload"] != workload_name or rec["updates_per_step"] != updates_per_step:
             return None
+        if rec.get("library_sha16") != library_sha16():  # taken on another build of the library: not quoted
+            return {"withheld": "profiles/window_probe.json was taken on another build of the library",
+                    "library_sha16": rec.get("library_sha16"), "running_library_sha16": library_sha16()}
         pose, records = rec["pose_line_bytes_per_unit"], rec["record_bytes_per_unit"]
         low = pose * units_per_launch
         high = traffic - records * units_per_launch
@@ -612,7 +625,9 @@ def main():
         }
         if traffic:
             only = hbm_only_bracket(workload_name, args.updates_per_step, d_units / max(launches, 1), traffic)
-            if only:
+            if only and "withheld" in only:
+                roofline["hbm_only"] = only
+            elif only:
                 only["low_frac"] = only["low_bytes_per_launch"] / kern_s / 1e9 / HBM_PEAK_GBS
                 only["high_frac"] = only["high_bytes_per_launch"] / kern_s / 1e9 / HBM_PEAK_GBS
                 roofline["hbm_only"] = only
