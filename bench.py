@@ -70,6 +70,8 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--rebuild-every", type=int, default=1, help="steps between cumulative-pose rebuilds")
     ap.add_argument("--threads-per-chain", type=int, default=0)
+    ap.add_argument("--serial-program", type=int, default=0, choices=[0, 1, 2],
+                    help="mcmcgpu_config.serial_program: 0 = the library's choice, 1 = called, 2 = compiled into the kernel")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-plaza", action="store_true")
@@ -192,7 +194,7 @@ def child_argv(args):
             "--no-plaza", "--no-live-traffic", "--chains", str(args.chains), "--updates-per-step", str(args.updates_per_step),
             "--report-every", str(args.report_every), "--timesteps", str(args.timesteps), "--landmarks", str(args.landmarks),
             "--k-nearest", str(args.k_nearest), "--seed", str(args.seed), "--rebuild-every", str(args.rebuild_every),
-            "--threads-per-chain", str(args.threads_per_chain), "--split-slices", str(args.split_slices),
+            "--threads-per-chain", str(args.threads_per_chain), "--serial-program", str(args.serial_program), "--split-slices", str(args.split_slices),
             "--range-stddev", repr(args.range_stddev), "--bearing-stddev", repr(args.bearing_stddev),
             "--beta-min", repr(args.beta_min), "--beta", repr(args.beta)]
     return argv, 3  # launches (steps + warm-up) of that run
@@ -456,7 +458,7 @@ def main():
     torch.cuda.set_stream(stream)
     g = capi.McmcGpu(C, T, F, N, device=local_rank,
                      threads_per_chain=args.threads_per_chain, stream=stream.cuda_stream, range_bearing=bearing,
-                     max_split_slices=args.split_slices)
+                     max_split_slices=args.split_slices, serial_program=args.serial_program)
     g.upload_problem(problem["ctrl_mean"], problem["ctrl_std"], problem["obs_t"], problem["obs_f"],
                      problem["obs_mean"], problem["obs_std"], F)
     if bearing:

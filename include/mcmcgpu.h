@@ -43,7 +43,7 @@ typedef struct mcmcgpu_config {
   uint32_t max_timesteps;     /* capacity for controls (state edges) */
   uint32_t max_features;      /* capacity for landmarks */
   uint32_t max_observations;  /* capacity for range readings */
-  uint32_t threads_per_chain; /* workgroup size; 0 -> 256 (128 when max_observations <= 4096 and max_chains > 256); power of two in [64, 1024] */
+  uint32_t threads_per_chain; /* workgroup size; 0 -> 256 (64 when max_observations <= 32768 and max_chains > 256); power of two in [64, 1024] */
   /* Order of the two draws inside a landmark proposal.  The reference leaves it
    * unsequenced (src/planar_robot/range_bearing_model.hpp:155-159): 1 = uniform
    * then normal (what g++ emits), 0 = normal then uniform (clang). */
@@ -65,8 +65,9 @@ typedef struct mcmcgpu_config {
   uint32_t split_commit_min_poses;
   /* Where the serial part of an update (selection, proposal, accept test; the reference's
    * src/slam/mcmc_slam.hpp:339-418 outside the loop over readings) is compiled: 0 = the library
-   * chooses (compiled into the kernel when a launch has at most 256 chains, so that every chain
-   * has a CU to itself and its serial part is the launch's critical path; a called function
+   * chooses (compiled into the kernel when a launch has at most 1024 wavefronts -- 256 chains of 256
+   * lanes, 1024 chains of 64 -- so that every wavefront has a SIMD to itself and the serial part is
+   * the launch's critical path; a called function
    * otherwise, which keeps the registers of the loop over readings free); 1 = always called;
    * 2 = compiled in whenever the workgroup has at most 256 lanes.  Results do not depend on it. */
   uint32_t serial_program;

@@ -229,13 +229,14 @@ __device__ unsigned long long g_phase_cycles[16];
 #define MG_MARK(S, slot)
 #endif
 
-struct Shared {
-  long long phase[16];
-  RngState rng;
-  // driver state (lane 0 only)
+// What the serial program (the "driver") keeps between its steps.  When the program is a called piece run
+// by one lane it lives in the chain's LDS block (Shared::drv); when it is compiled into the kernel and run
+// by a whole wavefront on the same data (advance_kernel's SOLO variant) it is a local object of the kernel,
+// i.e. registers: a lone wavefront waits out every LDS round trip, and the program reads these all the time.
+struct DriverState {
   int stage;
   uint32_t tn, upto, arr, arr_end, steps_left, steps_per_ts, end_left, end_done, end_inflight;
-  uint32_t awaiting;  // an evaluation has been posted and its result not yet taken (piece_step)
+  uint32_t awaiting;  // an evaluation has been posted and its result not yet taken (step_with)
   uint32_t Tcur, nf;
   double ll;
   double beta;    // inverse temperature of this chain (1 = the reference's sampler)
@@ -255,6 +256,12 @@ struct Shared {
   uint32_t idx;
   double q[3];
   int accept;
+};
+
+struct Shared {
+  long long phase[16];
+  RngState rng;
+  DriverState drv;
   // evaluation scratch
   uint32_t nact;
   uint32_t act[kActCap];
@@ -315,11 +322,11 @@ MG_DEV void append_pose(const Dev& d, uint32_t c, uint32_t Tcur, const Pose& rel
 
 // The chain's two weight trees as the driver sees them: global arrays, with their tops in LDS when
 // the kernel has set copies up (see advance_kernel).
-MG_DEV wt::Cached state_tree(const Dev& d, uint32_t c, const Shared& S) {
-  return wt::Cached{d.sw + size_t(c) * d.Tcap, S.sw_top, S.sw_shift};
+MG_DEV wt::Cached state_tree(const Dev& d, uint32_t c, const DriverState& D) {
+  return wt::Cached{d.sw + size_t(c) * d.Tcap, D.sw_top, D.sw_shift};
 }
-MG_DEV wt::Cached landmark_tree(const Dev& d, uint32_t c, const Shared& S) {
-  return wt::Cached{d.fw + size_t(c) * d.Fcap, S.fw_top, S.fw_shift};
+MG_DEV wt::Cached landmark_tree(const Dev& d, uint32_t c, const DriverState& D) {
+  return wt::Cached{d.fw + size_t(c) * d.Fcap, D.fw_top, D.fw_shift};
 }
 
 // ---------------------------------------------------------------------------
@@ -1112,7 +1119,7 @@ MG_DEV void load_control(const Dev& d, uint32_t t, double mu[3], double sd[3], d
   log_det = d.cld[t];
 }
 
-MG_DEV void write_trace(const Dev& d, uint32_t c, Shared& S, int kind, uint32_t idx, const double q[3], double llr,
+MG_DEV void write_trace(const Dev& d, uint32_t c, const DriverState& D, int kind, uint32_t idx, const double q[3], double llr,
                         int accepted) {
   if (!d.trace) return;
   const uint32_t n = d.trace_n[c];
@@ -1125,7 +1132,7 @@ MG_DEV void write_trace(const Dev& d, uint32_t c, Shared& S, int kind, uint32_t 
     r.proposed[1] = q[1];
     r.proposed[2] = q[2];
     r.log_ratio = llr;
-    r.log_likelihood = S.ll;
+    r.log_likelihood = D.ll;
   }
   d.trace_n[c] = n + 1;
 }
@@ -1150,8 +1157,8 @@ MG_DEV Vec2 propose_landmark(const Dev& d, R& rng, const Reading& m) {
 }
 
 // mcmc_slam::add_state_edge (mcmc_slam.hpp:227-246) for edge Tcur
-MG_DEV void driver_add_state_edge(const Dev& d, uint32_t c, Shared& S) {
-  const uint32_t t = S.Tcur;
+MG_DEV void driver_add_state_edge(const Dev& d, uint32_t c, DriverState& D) {
+  const uint32_t t = D.Tcur;
   double mu[3], sd[3], ld;
   load_control(d, t, mu, sd, ld);
   // with an initialiser its estimate is taken, else the proposal's initial value (:233-237)
@@ -1164,21 +1171,21 @@ MG_DEV void driver_add_state_edge(const Dev& d, uint32_t c, Shared& S) {
   append_pose(d, c, t, est);
   const double lp = control_log_pdf(mu, sd, ld, est);
   d.clp[ri] = lp;
-  wt::push_back(state_tree(d, c, S), t, edge_weight_from_log_pdf(lp, 3.0, nullptr));
-  S.w_dirty = 1;
-  S.ll += lp;
-  S.llc += lp;
-  S.Tcur = t + 1;
+  wt::push_back(state_tree(d, c, D), t, edge_weight_from_log_pdf(lp, 3.0, nullptr));
+  D.w_dirty = 1;
+  D.ll += lp;
+  D.llc += lp;
+  D.Tcur = t + 1;
 }
 
 // Weight totals of both trees (mcmc_slam.hpp:342-343, :400-401).  They only
 // change when a weight changes, so they are kept until then; recomputing them
 // gives bit-identical values.
-MG_DEV void refresh_totals(const Dev& d, uint32_t c, Shared& S) {
-  if (!S.w_dirty) return;
-  S.Ws = wt::total(state_tree(d, c, S), S.Tcur);
-  S.Wf = wt::total(landmark_tree(d, c, S), S.nf);
-  S.w_dirty = 0;
+MG_DEV void refresh_totals(const Dev& d, uint32_t c, DriverState& D) {
+  if (!D.w_dirty) return;
+  D.Ws = wt::total(state_tree(d, c, D), D.Tcur);
+  D.Wf = wt::total(landmark_tree(d, c, D), D.nf);
+  D.w_dirty = 0;
 }
 
 // Selection and proposal of one update (mcmc_slam.hpp:339-368, :375-382).
@@ -1197,11 +1204,11 @@ MG_DEV uint32_t draw_index(const wt::Cached& tree, uint32_t n, double value) {
 }
 
 template <class R>
-MG_DEV bool driver_begin_update(const Dev& d, uint32_t c, Shared& S, R& rng) {
-  const wt::Cached sw = state_tree(d, c, S), fw = landmark_tree(d, c, S);
+MG_DEV bool driver_begin_update(const Dev& d, uint32_t c, Shared& S, DriverState& D, R& rng) {
+  const wt::Cached sw = state_tree(d, c, D), fw = landmark_tree(d, c, D);
   MG_MARK_BEGIN();
-  refresh_totals(d, c, S);
-  const double Ws = S.Ws, Wf = S.Wf;
+  refresh_totals(d, c, D);
+  const double Ws = D.Ws, Wf = D.Wf;
   if (Ws == 0 && Wf == 0) return false;
   uint32_t retry = 0;
   MG_MARK(S, 8);
@@ -1210,10 +1217,10 @@ MG_DEV bool driver_begin_update(const Dev& d, uint32_t c, Shared& S, R& rng) {
   if ((Ws + Wf) * which < Ws) {
     uint32_t t;
     do {
-      t = draw_index<R>(sw, S.Tcur, Ws * rng.uniform());
-    } while (t >= S.Tcur && ++retry < kMaxRetry);
-    if (t >= S.Tcur) {
-      S.failed = 1;
+      t = draw_index<R>(sw, D.Tcur, Ws * rng.uniform());
+    } while (t >= D.Tcur && ++retry < kMaxRetry);
+    if (t >= D.Tcur) {
+      D.failed = 1;
       return false;
     }
     MG_MARK(S, 10);
@@ -1226,37 +1233,37 @@ MG_DEV bool driver_begin_update(const Dev& d, uint32_t c, Shared& S, R& rng) {
     MG_MARK(S, 11);
     const Pose q = control_inv_observe(v);
     MG_MARK(S, 12);
-    S.new_pll = control_log_pdf(mu, sd, ld, q);
-    S.old_pll = old_pll;
+    D.new_pll = control_log_pdf(mu, sd, ld, q);
+    D.old_pll = old_pll;
     MG_MARK(S, 13);
-    S.op = OP_EVAL_STATE;
-    S.idx = t;
-    S.q[0] = q.x;
-    S.q[1] = q.y;
-    S.q[2] = q.th;
+    D.op = OP_EVAL_STATE;
+    D.idx = t;
+    D.q[0] = q.x;
+    D.q[1] = q.y;
+    D.q[2] = q.th;
   } else {
     uint32_t f;
     do {
-      f = draw_index<R>(fw, S.nf, Wf * rng.uniform());
-    } while (f >= S.nf && ++retry < kMaxRetry);
-    if (f >= S.nf) {
-      S.failed = 1;
+      f = draw_index<R>(fw, D.nf, Wf * rng.uniform());
+    } while (f >= D.nf && ++retry < kMaxRetry);
+    if (f >= D.nf) {
+      D.failed = 1;
       return false;
     }
     const size_t fi = size_t(c) * d.Fcap + f;
     const Reading m = parent_reading(d, fi);
     const Vec2 q = propose_landmark(d, rng, m);
-    S.new_pll = reading_proposal_log_pdf(m, q);
-    S.old_pll = reading_proposal_log_pdf(m, Vec2{d.fex[fi], d.fey[fi]});
-    S.op = OP_EVAL_FEATURE;
-    S.idx = f;
-    S.q[0] = q.x;
-    S.q[1] = q.y;
-    S.q[2] = 0.0;
+    D.new_pll = reading_proposal_log_pdf(m, q);
+    D.old_pll = reading_proposal_log_pdf(m, Vec2{d.fex[fi], d.fey[fi]});
+    D.op = OP_EVAL_FEATURE;
+    D.idx = f;
+    D.q[0] = q.x;
+    D.q[1] = q.y;
+    D.q[2] = 0.0;
     MG_MARK(S, 14);
   }
-  S.pending = PEND_UPDATE;
-  S.use_weight = 1;
+  D.pending = PEND_UPDATE;
+  D.use_weight = 1;
   return true;
 }
 
@@ -1264,22 +1271,22 @@ MG_DEV bool driver_begin_update(const Dev& d, uint32_t c, Shared& S, R& rng) {
 // observation part of the log ratio is known.  Returns the accept decision;
 // the pose table of an accepted state edge is moved afterwards by all lanes.
 template <class R>
-MG_DEV bool driver_finish_update(const Dev& d, uint32_t c, Shared& S, R& rng, double obs_ratio) {
-  const bool is_state = (S.op == OP_EVAL_STATE);
+MG_DEV bool driver_finish_update(const Dev& d, uint32_t c, DriverState& D, R& rng, double obs_ratio) {
+  const bool is_state = (D.op == OP_EVAL_STATE);
   const double dim = is_state ? 3.0 : 2.0;
-  const double proposal_log_ratio = S.new_pll - S.old_pll;
+  const double proposal_log_ratio = D.new_pll - D.old_pll;
   // state edge: the control term of :436-438 is the same pair of numbers
-  const double log_ratio = is_state ? (S.new_pll - S.old_pll) + obs_ratio : obs_ratio;
+  const double log_ratio = is_state ? (D.new_pll - D.old_pll) + obs_ratio : obs_ratio;
   // the three exponentials of the step (:389, :397, :408) have their arguments ready together: a
   // wavefront takes one each in three lanes, one lane takes them one after the other; same values
-  const double new_log_weight = log(dim) - S.new_pll / dim;  // edge_log_weight, :160-162
-  const double old_log_weight = log(dim) - S.old_pll / dim;
+  const double new_log_weight = log(dim) - D.new_pll / dim;  // edge_log_weight, :160-162
+  const double old_log_weight = log(dim) - D.old_pll / dim;
   double normaliser = 1.0;
   // a tempered replica targets controls x readings^beta: the readings' part of the ratio is
   // weighed by the inverse temperature; with beta = 1 this is log_ratio bit for bit
-  const double tempered = is_state ? (S.new_pll - S.old_pll) + S.beta * obs_ratio : S.beta * obs_ratio;
+  const double tempered = is_state ? (D.new_pll - D.old_pll) + D.beta * obs_ratio : D.beta * obs_ratio;
   double accept_log_ratio = tempered - proposal_log_ratio;
-  if (S.use_weight) accept_log_ratio += new_log_weight - old_log_weight;
+  if (D.use_weight) accept_log_ratio += new_log_weight - old_log_weight;
   double new_weight, old_weight, accept_bar;
 #if defined(__HIP_DEVICE_COMPILE__)
   if (R::kWave) {
@@ -1292,13 +1299,13 @@ MG_DEV bool driver_finish_update(const Dev& d, uint32_t c, Shared& S, R& rng, do
 #endif
   {
     new_weight = exp(new_log_weight);
-    old_weight = S.use_weight ? exp(old_log_weight) : 0.0;
+    old_weight = D.use_weight ? exp(old_log_weight) : 0.0;
     accept_bar = exp(accept_log_ratio);
   }
-  const wt::Cached sw = state_tree(d, c, S), fw = landmark_tree(d, c, S);
-  if (S.use_weight) {
-    refresh_totals(d, c, S);
-    const double weight_sum = S.Ws + S.Wf;
+  const wt::Cached sw = state_tree(d, c, D), fw = landmark_tree(d, c, D);
+  if (D.use_weight) {
+    refresh_totals(d, c, D);
+    const double weight_sum = D.Ws + D.Wf;
     normaliser += (new_weight - old_weight) / weight_sum;
   }
 #ifdef MG_DIAG_REJECT_ALL  // diagnostic builds: the chains stay where they are whatever the streams computed
@@ -1308,32 +1315,32 @@ MG_DEV bool driver_finish_update(const Dev& d, uint32_t c, Shared& S, R& rng, do
 #endif
   if (accept) {
     if (is_state) {
-      S.llc += S.new_pll - S.old_pll;
-      d.clp[size_t(c) * d.Tcap + S.idx] = S.new_pll;
-      wt::set(sw, S.Tcur, S.idx, new_weight);
+      D.llc += D.new_pll - D.old_pll;
+      d.clp[size_t(c) * d.Tcap + D.idx] = D.new_pll;
+      wt::set(sw, D.Tcur, D.idx, new_weight);
       // the relative pose itself is stored after commit_state_edge has moved
       // the pose table (that needs the old angle)
     } else {
-      const size_t fi = size_t(c) * d.Fcap + S.idx;
-      d.fex[fi] = S.q[0];
-      d.fey[fi] = S.q[1];
-      wt::set(fw, S.nf, S.idx, new_weight);
+      const size_t fi = size_t(c) * d.Fcap + D.idx;
+      d.fex[fi] = D.q[0];
+      d.fey[fi] = D.q[1];
+      wt::set(fw, D.nf, D.idx, new_weight);
     }
-    S.w_dirty = 1;
-    S.ll += log_ratio;
+    D.w_dirty = 1;
+    D.ll += log_ratio;
   }
-  write_trace(d, c, S, is_state ? 0 : 1, S.idx, S.q, log_ratio, accept ? 1 : 0);
+  write_trace(d, c, D, is_state ? 0 : 1, D.idx, D.q, log_ratio, accept ? 1 : 0);
   return accept;
 }
 
 // One arrival during growth (mcmc_slam.hpp:283-331).  Returns true when a
 // re-parenting update was posted and needs the workgroup.
 template <class R>
-MG_DEV bool driver_arrival(const Dev& d, uint32_t c, Shared& S, R& rng, uint32_t o) {
+MG_DEV bool driver_arrival(const Dev& d, uint32_t c, DriverState& D, R& rng, uint32_t o) {
   const ObsRec rec = d.orec[o];
   const uint32_t f = rec.f;
   const size_t fi = size_t(c) * d.Fcap + f;
-  const uint32_t t = S.tn;
+  const uint32_t t = D.tn;
   const Reading m = load_reading(d, o);
   const double mu = rec.mu;
   if (o == d.foff[f]) {  // first reading of this landmark: add_feature_edge, :248-270
@@ -1354,10 +1361,10 @@ MG_DEV bool driver_arrival(const Dev& d, uint32_t c, Shared& S, R& rng, uint32_t
     d.fpt[fi] = t;
     keep_parent_pose(d, c, fi, t);
     d.flast[fi] = t;
-    wt::push_back(landmark_tree(d, c, S), f, edge_weight_from_log_pdf(reading_proposal_log_pdf(m, est), 2.0, nullptr));
-    S.w_dirty = 1;
-    S.ll += reading_log_pdf(m, est);
-    S.nf = f + 1;
+    wt::push_back(landmark_tree(d, c, D), f, edge_weight_from_log_pdf(reading_proposal_log_pdf(m, est), 2.0, nullptr));
+    D.w_dirty = 1;
+    D.ll += reading_log_pdf(m, est);
+    D.nf = f + 1;
     return false;
   }
   const uint32_t rel = o - d.foff[f];
@@ -1365,7 +1372,7 @@ MG_DEV bool driver_arrival(const Dev& d, uint32_t c, Shared& S, R& rng, uint32_t
   d.flast[fi] = t;
   const Vec2 w = act(parent_frame(d, fi), Vec2{d.fex[fi], d.fey[fi]});
   const Vec2 est = act_inverse(world_pose(d, c, t), w);
-  S.ll += reading_log_pdf(m, est);
+  D.ll += reading_log_pdf(m, est);
   const double par_mu = d.fpmu[fi];
   if (fabs(mu) < fabs(par_mu)) {  // more_accurate_than, range_bearing_model.hpp:141-143
     d.fpar[fi] = rel;
@@ -1376,16 +1383,16 @@ MG_DEV bool driver_arrival(const Dev& d, uint32_t c, Shared& S, R& rng, uint32_t
     d.fey[fi] = est.y;
     // update(feature_edge, false), :320
     const Vec2 q = propose_landmark(d, rng, m);
-    S.new_pll = reading_proposal_log_pdf(m, q);
-    S.old_pll = reading_proposal_log_pdf(m, est);
-    S.op = OP_EVAL_FEATURE;
-    S.idx = f;
-    S.q[0] = q.x;
-    S.q[1] = q.y;
-    S.q[2] = 0.0;
-    S.pending = PEND_REPARENT;
-    S.use_weight = 0;
-    S.rp_obs = o;
+    D.new_pll = reading_proposal_log_pdf(m, q);
+    D.old_pll = reading_proposal_log_pdf(m, est);
+    D.op = OP_EVAL_FEATURE;
+    D.idx = f;
+    D.q[0] = q.x;
+    D.q[1] = q.y;
+    D.q[2] = 0.0;
+    D.pending = PEND_REPARENT;
+    D.use_weight = 0;
+    D.rp_obs = o;
     return true;
   }
   return false;
@@ -1396,85 +1403,85 @@ MG_DEV bool driver_arrival(const Dev& d, uint32_t c, Shared& S, R& rng, uint32_t
 // more updates than one interval, every chain leaves a summary of itself at
 // each interval boundary, so the caller gets the same report lines from one
 // long launch as from many short ones.
-MG_DEV void driver_report(const Dev& d, uint32_t c, Shared& S) {
+MG_DEV void driver_report(const Dev& d, uint32_t c, const DriverState& D) {
   if (!d.snap_out || d.snap_every == 0) return;
-  if (S.end_done % d.snap_every != 0 && S.end_left != 0) return;
-  const uint32_t slot = (S.end_done + d.snap_every - 1) / d.snap_every - 1;
+  if (D.end_done % d.snap_every != 0 && D.end_left != 0) return;
+  const uint32_t slot = (D.end_done + d.snap_every - 1) / d.snap_every - 1;
   mcmcgpu_chain_summary& r = d.snap_out[size_t(slot) * d.C + c];
-  r.log_likelihood = S.ll;
-  r.updates = uint32_t(d.n_updates[c] + S.n_upd);
-  r.accepts = uint32_t(d.n_accepts[c] + S.n_acc);
+  r.log_likelihood = D.ll;
+  r.updates = uint32_t(d.n_updates[c] + D.n_upd);
+  r.accepts = uint32_t(d.n_accepts[c] + D.n_acc);
 }
 
 // Runs lane 0's program until it needs the workgroup (a request is posted in
-// S.op) or is finished (S.op = OP_END).
+// D.op) or is finished (D.op = OP_END).
 template <class R>
-MG_DEV void driver_advance(const Dev& d, uint32_t c, Shared& S, R& rng) {
+MG_DEV void driver_advance(const Dev& d, uint32_t c, Shared& S, DriverState& D, R& rng) {
   for (;;) {
-    if (S.failed) {
-      S.op = OP_END;
+    if (D.failed) {
+      D.op = OP_END;
       return;
     }
-    switch (S.stage) {
+    switch (D.stage) {
       case ST_EDGE: {
-        if (S.tn > S.upto) {
-          S.stage = ST_END_STEPS;
+        if (D.tn > D.upto) {
+          D.stage = ST_END_STEPS;
           break;
         }
         MG_MARK_BEGIN();
-        if (S.tn > 0) driver_add_state_edge(d, c, S);
-        S.arr = d.toff[S.tn];
-        S.arr_end = d.toff[S.tn + 1];
-        S.stage = ST_ARRIVALS;
+        if (D.tn > 0) driver_add_state_edge(d, c, D);
+        D.arr = d.toff[D.tn];
+        D.arr_end = d.toff[D.tn + 1];
+        D.stage = ST_ARRIVALS;
         MG_MARK(S, 15);
         break;
       }
       case ST_ARRIVALS: {
         MG_MARK_BEGIN();
-        while (S.arr < S.arr_end) {
-          const uint32_t o = d.tobs[S.arr++];
-          if (driver_arrival(d, c, S, rng, o)) {
+        while (D.arr < D.arr_end) {
+          const uint32_t o = d.tobs[D.arr++];
+          if (driver_arrival(d, c, D, rng, o)) {
             MG_MARK(S, 15);
             return;
           }
         }
-        S.steps_left = S.steps_per_ts;
-        S.stage = ST_STEPS;
+        D.steps_left = D.steps_per_ts;
+        D.stage = ST_STEPS;
         MG_MARK(S, 15);
         break;
       }
       case ST_STEPS:
-        while (S.steps_left > 0) {
-          --S.steps_left;
-          ++S.n_upd;
-          if (driver_begin_update(d, c, S, rng)) return;
+        while (D.steps_left > 0) {
+          --D.steps_left;
+          ++D.n_upd;
+          if (driver_begin_update(d, c, S, D, rng)) return;
         }
-        S.stage = ST_NEXT;
+        D.stage = ST_NEXT;
         break;
       case ST_NEXT:
-        ++S.tn;
-        S.stage = ST_EDGE;
+        ++D.tn;
+        D.stage = ST_EDGE;
         break;
       case ST_END_STEPS:
         for (;;) {
-          if (S.end_inflight) {  // the update posted last time round has been finished by the workgroup
-            S.end_inflight = 0;
-            driver_report(d, c, S);
+          if (D.end_inflight) {  // the update posted last time round has been finished by the workgroup
+            D.end_inflight = 0;
+            driver_report(d, c, D);
           }
-          if (S.end_left == 0) break;
-          --S.end_left;
-          ++S.n_upd;
-          ++S.end_done;
-          if (driver_begin_update(d, c, S, rng)) {
-            S.end_inflight = 1;
+          if (D.end_left == 0) break;
+          --D.end_left;
+          ++D.n_upd;
+          ++D.end_done;
+          if (driver_begin_update(d, c, S, D, rng)) {
+            D.end_inflight = 1;
             return;
           }
-          driver_report(d, c, S);  // nothing could be updated: the step is over already
+          driver_report(d, c, D);  // nothing could be updated: the step is over already
         }
-        S.stage = ST_DONE;
+        D.stage = ST_DONE;
         break;
       default:
-        S.op = OP_END;
+        D.op = OP_END;
         return;
     }
   }
@@ -1484,45 +1491,50 @@ MG_DEV void driver_advance(const Dev& d, uint32_t c, Shared& S, R& rng) {
 // kernels
 
 // Loads / stores the per-chain state that lives in LDS while a kernel runs.
-MG_DEV void chain_state_load(const Dev& d, uint32_t c, Shared& S) {
+// D is the driver's state: the block's copy in LDS, filled by lane 0, or (EVERY_LANE) an object of the
+// kernel that every lane fills for itself.
+template <bool EVERY_LANE = false>
+MG_DEV void chain_state_load(const Dev& d, uint32_t c, Shared& S, DriverState& D) {
   for (uint32_t i = threadIdx.x; i < 624; i += blockDim.x) S.rng.mt[i] = d.mt[size_t(c) * 624 + i];
   if (threadIdx.x == 0) {
     S.rng.idx = d.mti[c];
     S.rng.has_saved = d.nflag[c];
     S.rng.saved = d.nsaved[c];
-    S.nf = d.nf[c];
-    S.ll = d.ll[c];
-    S.beta = d.beta[c];
-    S.llc = d.llc[c];
-    S.n_upd = 0;
-    S.n_acc = 0;
-    S.n_units = 0;
-    S.n_state = 0;
-    S.n_moved = 0;
-    S.failed = 0;
-    S.w_dirty = 1;
-    S.sw_top = S.fw_top = 0;
-    S.sw_shift = S.fw_shift = 0;
-    S.pending = PEND_NONE;
     for (int i = 0; i < 16; ++i) S.phase[i] = 0;
   }
+  if (EVERY_LANE || threadIdx.x == 0) {
+    D.nf = d.nf[c];
+    D.ll = d.ll[c];
+    D.beta = d.beta[c];
+    D.llc = d.llc[c];
+    D.n_upd = 0;
+    D.n_acc = 0;
+    D.n_units = 0;
+    D.n_state = 0;
+    D.n_moved = 0;
+    D.failed = 0;
+    D.w_dirty = 1;
+    D.sw_top = D.fw_top = 0;
+    D.sw_shift = D.fw_shift = 0;
+    D.pending = PEND_NONE;
+  }
 }
-MG_DEV void chain_state_store(const Dev& d, uint32_t c, Shared& S) {
+MG_DEV void chain_state_store(const Dev& d, uint32_t c, Shared& S, const DriverState& D) {
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < 624; i += blockDim.x) d.mt[size_t(c) * 624 + i] = S.rng.mt[i];
   if (threadIdx.x == 0) {
     d.mti[c] = S.rng.idx;
     d.nflag[c] = S.rng.has_saved;
     d.nsaved[c] = S.rng.saved;
-    d.nf[c] = S.nf;
-    d.ll[c] = S.ll;
-    d.llc[c] = S.llc;
-    d.n_updates[c] += S.n_upd;
-    d.n_accepts[c] += S.n_acc;
-    d.n_units[c] += S.n_units;
-    d.n_state_props[c] += S.n_state;
-    d.n_moved[c] += S.n_moved;
-    if (S.failed) d.errflag[c] = 1;
+    d.nf[c] = D.nf;
+    d.ll[c] = D.ll;
+    d.llc[c] = D.llc;
+    d.n_updates[c] += D.n_upd;
+    d.n_accepts[c] += D.n_acc;
+    d.n_units[c] += D.n_units;
+    d.n_state_props[c] += D.n_state;
+    d.n_moved[c] += D.n_moved;
+    if (D.failed) d.errflag[c] = 1;
   }
 }
 
@@ -1540,22 +1552,15 @@ MG_DEV void chain_state_store(const Dev& d, uint32_t c, Shared& S) {
 // around it are calls: a called evaluation saves and restores the callee-saved half of its 128
 // registers in every lane at every proposal -- about 100 KB each way per proposal, an eighth of
 // the kernel's memory traffic -- while the serial pieces, called by one lane, save next to nothing.
+// `units`: readings the evaluation went through (the same number in every lane).
 template <bool RB>
 MG_DEV double inline_eval(DevArgs dp, SharedLds sp, uint32_t c, int op, uint32_t idx, double qx, double qy,
-                          double qth, uint32_t nf) {
+                          double qth, uint32_t nf, unsigned long long& units) {
   const Dev& d = *(const Dev*)dp;
   Shared& S = *(Shared*)sp;
-  unsigned long long units = 0;
-  double r;
-  if (op == OP_EVAL_STATE)
-    r = eval_state_edge<RB>(d, c, S, idx, Pose{qx, qy, qth}, nf, units);
-  else
-    r = eval_feature_edge<RB>(d, c, S, idx, Vec2{qx, qy}, units);
-  if (threadIdx.x == 0) {
-    S.n_units += units;
-    if (op == OP_EVAL_STATE) ++S.n_state;
-  }
-  return r;
+  units = 0;
+  if (op == OP_EVAL_STATE) return eval_state_edge<RB>(d, c, S, idx, Pose{qx, qy, qth}, nf, units);
+  return eval_feature_edge<RB>(d, c, S, idx, Vec2{qx, qy}, units);
 }
 
 // Lane 0's serial program between two requests to the workgroup, as ONE call: the end of the update
@@ -1563,38 +1568,38 @@ MG_DEV double inline_eval(DevArgs dp, SharedLds sp, uint32_t c, int op, uint32_t
 // state edge first needs all lanes for the pose table (OP_COMMIT) -- on to the next request.  One
 // call per update instead of two: a call costs a lone lane the save and reload of its registers.
 template <class R>
-MG_DEV void step_with(const Dev& d, uint32_t c, Shared& S, R& rng, double r) {
-  if (S.awaiting) {
-    S.awaiting = 0;
+MG_DEV void step_with(const Dev& d, uint32_t c, Shared& S, DriverState& D, R& rng, double r) {
+  if (D.awaiting) {
+    D.awaiting = 0;
 #ifdef MG_PHASE_TIMING
     const long long tf0 = clock64();
 #endif
-    const uint32_t idx = S.idx;
-    const bool accept = driver_finish_update(d, c, S, rng, r);
-    S.accept = accept ? 1 : 0;
-    if (S.pending == PEND_UPDATE) {
-      if (accept) ++S.n_acc;
+    const uint32_t idx = D.idx;
+    const bool accept = driver_finish_update(d, c, D, rng, r);
+    D.accept = accept ? 1 : 0;
+    if (D.pending == PEND_UPDATE) {
+      if (accept) ++D.n_acc;
     } else if (!accept) {  // rejected re-parenting update: reset the edge weight, :321-322
-      const uint32_t o = S.rp_obs;
+      const uint32_t o = D.rp_obs;
       const size_t fi = size_t(c) * d.Fcap + idx;
-      wt::set(landmark_tree(d, c, S), S.nf, idx,
+      wt::set(landmark_tree(d, c, D), D.nf, idx,
               edge_weight_from_log_pdf(reading_proposal_log_pdf(load_reading(d, o), Vec2{d.fex[fi], d.fey[fi]}), 2.0,
                                        nullptr));
-      S.w_dirty = 1;
+      D.w_dirty = 1;
     }
-    S.pending = PEND_NONE;
+    D.pending = PEND_NONE;
 #ifdef MG_PHASE_TIMING
     const long long tf1 = clock64();
     S.phase[4] += tf1 - tf0;  // the accept test's share of this call; the kernel books the whole call to slot 0
     S.phase[0] -= tf1 - tf0;
 #endif
-    if (S.op == OP_EVAL_STATE && accept) {
-      S.op = OP_COMMIT;
+    if (D.op == OP_EVAL_STATE && accept) {
+      D.op = OP_COMMIT;
       return;
     }
   }
-  driver_advance(d, c, S, rng);
-  if (S.op == OP_EVAL_STATE || S.op == OP_EVAL_FEATURE) S.awaiting = 1;
+  driver_advance(d, c, S, D, rng);
+  if (D.op == OP_EVAL_STATE || D.op == OP_EVAL_FEATURE) D.awaiting = 1;
 }
 
 // WAVE: the body is run by all 64 lanes of a wavefront on the same data (every lane computes and
@@ -1608,7 +1613,7 @@ MG_DEV void step_body(DevArgs dp, SharedLds sp, uint32_t c, double r) {
   const long long t_in = clock64();
 #endif
   SerialRng rng{S.rng};
-  step_with(d, c, S, rng, r);
+  step_with(d, c, S, S.drv, rng, r);
 #ifdef MG_PHASE_TIMING
   S.phase[7] += clock64() - t_in;  // slot 7: first to last instruction of the body (the call is the rest)
 #endif
@@ -1617,15 +1622,16 @@ MG_DEV void step_body(DevArgs dp, SharedLds sp, uint32_t c, double r) {
 #if defined(__HIP_DEVICE_COMPILE__)
 // The body run by all 64 lanes of a wavefront on the same data (every lane computes and stores the
 // same values), which lets the generator hand out its words from a window held in the lanes
-// (WaveRng).  The window object lives in the kernel's registers from launch to end: one fetch of
-// 64 words serves several updates.  Same results as the one-lane body.
-MG_DEV void step_body_wave(DevArgs dp, SharedLds sp, uint32_t c, double r, WaveRng& rng) {
+// (WaveRng).  The window object and the driver's state D live in the kernel's registers from launch
+// to end: one fetch of 64 words serves several updates, and the state machine never waits for LDS.
+// Same results as the one-lane body.
+MG_DEV void step_body_wave(DevArgs dp, SharedLds sp, uint32_t c, double r, WaveRng& rng, DriverState& D) {
   const Dev& d = *(const Dev*)dp;
   Shared& S = *(Shared*)sp;
 #ifdef MG_PHASE_TIMING
   const long long t_in = clock64();
 #endif
-  step_with(d, c, S, rng, r);
+  step_with(d, c, S, D, rng, r);
 #ifdef MG_PHASE_TIMING
   S.phase[7] += clock64() - t_in;
 #endif
@@ -1634,22 +1640,21 @@ MG_DEV void step_body_wave(DevArgs dp, SharedLds sp, uint32_t c, double r, WaveR
 
 MG_PIECE void piece_step(DevArgs dp, SharedLds sp, uint32_t c, double r) { step_body(dp, sp, c, r); }
 
-MG_DEV void commit_body(DevArgs dp, SharedLds sp, uint32_t c, uint32_t idx, double qx, double qy, double qth,
-                        uint32_t Tcur) {
+// The pose table behind an accepted state edge and the edge's new relative pose (all lanes).
+MG_DEV void commit_body(DevArgs dp, uint32_t c, uint32_t idx, double qx, double qy, double qth, uint32_t Tcur,
+                        uint32_t nf) {
   const Dev& d = *(const Dev*)dp;
-  Shared& S = *(Shared*)sp;
-  commit_state_edge(d, c, idx, Pose{qx, qy, qth}, Tcur, S.nf);
+  commit_state_edge(d, c, idx, Pose{qx, qy, qth}, Tcur, nf);
   if (threadIdx.x == 0) {
     const size_t ri = size_t(c) * d.Tcap + idx;
     d.relx[ri] = qx;
     d.rely[ri] = qy;
     d.relth[ri] = qth;
-    S.n_moved += Tcur - idx;  // poses idx+1 .. Tcur rewritten
   }
 }
-MG_PIECE void piece_commit(DevArgs dp, SharedLds sp, uint32_t c, uint32_t idx, double qx, double qy, double qth,
-                           uint32_t Tcur) {
-  commit_body(dp, sp, c, idx, qx, qy, qth, Tcur);
+MG_PIECE void piece_commit(DevArgs dp, uint32_t c, uint32_t idx, double qx, double qy, double qth, uint32_t Tcur,
+                           uint32_t nf) {
+  commit_body(dp, c, idx, qx, qy, qth, Tcur, nf);
 }
 
 // grid = chains, block = threads_per_chain.  first_tn = the next timestep the
@@ -1671,27 +1676,40 @@ __global__ void __launch_bounds__(SOLO ? 256 : 1024) advance_kernel(Dev d, uint3
   const DevArgs dp = (DevArgs)__builtin_amdgcn_kernarg_segment_ptr();
   const SharedLds sp = (SharedLds)&S;
   const uint32_t c = blockIdx.x;
-  chain_state_load(d, c, S);
+  // the driver's state: in LDS for the called program; SOLO: in registers, every lane its own copy (the
+  // first wavefront's lanes run the program together and keep theirs equal; the other lanes never use it)
+  DriverState own;
+  DriverState& D = SOLO ? own : S.drv;
+  chain_state_load<SOLO>(d, c, S, D);
   {  // nodes beyond a tree's current size hold nothing yet; they are written (through) before they are read
     const double* sw = d.sw + size_t(c) * d.Tcap;
     const double* fw = d.fw + size_t(c) * d.Fcap;
     for (uint32_t j = threadIdx.x; j < tops.sw_n; j += blockDim.x) tree_tops[j] = sw[size_t(j) << tops.sw_shift];
     for (uint32_t j = threadIdx.x; j < tops.fw_n; j += blockDim.x) tree_tops[tops.sw_n + j] = fw[size_t(j) << tops.fw_shift];
   }
-  if (threadIdx.x == 0) {
-    S.sw_top = tops.sw_n ? uint32_t(uintptr_t((wt::LdsDoubles)&tree_tops[0])) : 0;
-    S.fw_top = tops.fw_n ? uint32_t(uintptr_t((wt::LdsDoubles)&tree_tops[tops.sw_n])) : 0;
-    S.sw_shift = tops.sw_shift;
-    S.fw_shift = tops.fw_shift;
-    S.Tcur = Tcur0;
-    S.tn = first_tn;
-    S.upto = upto;
-    S.steps_per_ts = steps_per_ts;
-    S.end_left = end_steps;
-    S.end_done = 0;
-    S.end_inflight = 0;
-    S.awaiting = 0;
-    S.stage = grow ? ST_EDGE : ST_END_STEPS;
+  if (SOLO || threadIdx.x == 0) {
+    D.sw_top = tops.sw_n ? uint32_t(uintptr_t((wt::LdsDoubles)&tree_tops[0])) : 0;
+    D.fw_top = tops.fw_n ? uint32_t(uintptr_t((wt::LdsDoubles)&tree_tops[tops.sw_n])) : 0;
+    D.sw_shift = tops.sw_shift;
+    D.fw_shift = tops.fw_shift;
+    D.Tcur = Tcur0;
+    D.tn = first_tn;
+    D.upto = upto;
+    D.steps_per_ts = steps_per_ts;
+    D.end_left = end_steps;
+    D.end_done = 0;
+    D.end_inflight = 0;
+    D.awaiting = 0;
+    D.stage = grow ? ST_EDGE : ST_END_STEPS;
+    D.op = OP_END;
+    D.idx = 0;
+    D.q[0] = D.q[1] = D.q[2] = 0.0;
+    D.accept = 0;
+    D.use_weight = 0;
+    D.new_pll = D.old_pll = 0.0;
+    D.rp_obs = 0;
+    D.Ws = D.Wf = 0.0;
+    D.arr = D.arr_end = D.steps_left = 0;
   }
   __syncthreads();
   MG_STAMP(tk0);
@@ -1703,7 +1721,18 @@ __global__ void __launch_bounds__(SOLO ? 256 : 1024) advance_kernel(Dev d, uint3
     MG_STAMP(td0);
     if (SOLO) {
 #if defined(__HIP_DEVICE_COMPILE__)
-      if (threadIdx.x < 64) step_body_wave(dp, sp, c, r, wave_rng);  // the first wavefront, all lanes on the same data
+      if (threadIdx.x < 64) {  // the first wavefront, all lanes on the same data
+        step_body_wave(dp, sp, c, r, wave_rng, D);
+        if (threadIdx.x == 0) {  // the request, where the other wavefronts find it
+          S.drv.op = D.op;
+          S.drv.idx = D.idx;
+          S.drv.q[0] = D.q[0];
+          S.drv.q[1] = D.q[1];
+          S.drv.q[2] = D.q[2];
+          S.drv.Tcur = D.Tcur;
+          S.drv.nf = D.nf;
+        }
+      }
 #endif
     } else {
       if (threadIdx.x == 0) piece_step(dp, sp, c, r);
@@ -1711,22 +1740,28 @@ __global__ void __launch_bounds__(SOLO ? 256 : 1024) advance_kernel(Dev d, uint3
     __syncthreads();
     MG_STAMP(td1);
     MG_PHASE_ADD(S, 0, td0, td1);
-    const int op = S.op;
+    const int op = S.drv.op;
     if (op == OP_END) break;
-    const uint32_t idx = S.idx;
-    const double qx = S.q[0], qy = S.q[1], qth = S.q[2];
-    const uint32_t Tcur = S.Tcur, nf = S.nf;
+    const uint32_t idx = S.drv.idx;
+    const double qx = S.drv.q[0], qy = S.drv.q[1], qth = S.drv.q[2];
+    const uint32_t Tcur = S.drv.Tcur, nf = S.drv.nf;
     if (op == OP_COMMIT) {  // the state edge just accepted: all lanes move the pose table, then lane 0 goes on
       if (SOLO)
-        commit_body(dp, sp, c, idx, qx, qy, qth, Tcur);
+        commit_body(dp, c, idx, qx, qy, qth, Tcur, nf);
       else
-        piece_commit(dp, sp, c, idx, qx, qy, qth, Tcur);
+        piece_commit(dp, c, idx, qx, qy, qth, Tcur, nf);
+      if (SOLO || threadIdx.x == 0) D.n_moved += Tcur - idx;  // poses idx+1 .. Tcur rewritten
       __syncthreads();
       MG_STAMP(tg1);
       MG_PHASE_ADD(S, 5, td1, tg1);
       continue;
     }
-    r = inline_eval<RB>(dp, sp, c, op, idx, qx, qy, qth, nf);
+    unsigned long long units;
+    r = inline_eval<RB>(dp, sp, c, op, idx, qx, qy, qth, nf, units);
+    if (SOLO || threadIdx.x == 0) {
+      D.n_units += units;
+      if (op == OP_EVAL_STATE) ++D.n_state;
+    }
 #if defined(__HIP_DEVICE_COMPILE__)
     // the sum is valid in lane 0; the first wavefront's lanes all run the serial program on it
     if (SOLO) r = wt::readlane_f64(r, 0);
@@ -1744,7 +1779,7 @@ __global__ void __launch_bounds__(SOLO ? 256 : 1024) advance_kernel(Dev d, uint3
     for (int i = 0; i < 16; ++i) atomicAdd(&g_phase_cycles[i], (unsigned long long)S.phase[i]);
   }
 #endif
-  chain_state_store(d, c, S);
+  chain_state_store(d, c, S, D);
 }
 
 // ---------------------------------------------------------------------------
@@ -1754,36 +1789,36 @@ __global__ void __launch_bounds__(SOLO ? 256 : 1024) advance_kernel(Dev d, uint3
 // of one proposal is cut into `slices` equal parts.  Same arithmetic per reading as the persistent
 // kernel; the partial sums of the slices are added in a fixed order.  Updates after growth.
 
-MG_DEV void ctl_to_shared(const Dev& d, uint32_t c, Shared& S, uint32_t Tcur) {
+MG_DEV void ctl_to_shared(const Dev& d, uint32_t c, DriverState& D, uint32_t Tcur) {
   const ChainCtl& k = d.ctl[c];
-  S.Tcur = Tcur;
-  S.Ws = k.Ws;
-  S.Wf = k.Wf;
-  S.w_dirty = k.w_dirty;
-  S.new_pll = k.new_pll;
-  S.old_pll = k.old_pll;
-  S.q[0] = k.q[0];
-  S.q[1] = k.q[1];
-  S.q[2] = k.q[2];
-  S.op = k.op;
-  S.idx = k.idx;
-  S.pending = k.pending;
-  S.use_weight = k.use_weight;
+  D.Tcur = Tcur;
+  D.Ws = k.Ws;
+  D.Wf = k.Wf;
+  D.w_dirty = k.w_dirty;
+  D.new_pll = k.new_pll;
+  D.old_pll = k.old_pll;
+  D.q[0] = k.q[0];
+  D.q[1] = k.q[1];
+  D.q[2] = k.q[2];
+  D.op = k.op;
+  D.idx = k.idx;
+  D.pending = k.pending;
+  D.use_weight = k.use_weight;
 }
-MG_DEV void shared_to_ctl(const Dev& d, uint32_t c, const Shared& S) {
+MG_DEV void shared_to_ctl(const Dev& d, uint32_t c, const DriverState& D) {
   ChainCtl& k = d.ctl[c];
-  k.Ws = S.Ws;
-  k.Wf = S.Wf;
-  k.w_dirty = S.w_dirty;
-  k.new_pll = S.new_pll;
-  k.old_pll = S.old_pll;
-  k.q[0] = S.q[0];
-  k.q[1] = S.q[1];
-  k.q[2] = S.q[2];
-  k.op = S.op;
-  k.idx = S.idx;
-  k.pending = S.pending;
-  k.use_weight = S.use_weight;
+  k.Ws = D.Ws;
+  k.Wf = D.Wf;
+  k.w_dirty = D.w_dirty;
+  k.new_pll = D.new_pll;
+  k.old_pll = D.old_pll;
+  k.q[0] = D.q[0];
+  k.q[1] = D.q[1];
+  k.q[2] = D.q[2];
+  k.op = D.op;
+  k.idx = D.idx;
+  k.pending = D.pending;
+  k.use_weight = D.use_weight;
 }
 
 // The serial ends of an update, one workgroup per chain: the END of update k -- sum of the slices,
@@ -1795,8 +1830,9 @@ __global__ void split_ends_kernel(Dev d_by_value, uint32_t Tcur, uint32_t slices
                                   uint32_t defer_commit) {
   MG_KERNEL_DEV(d);
   __shared__ Shared S;
+  DriverState& D = S.drv;
   const uint32_t c = blockIdx.x;
-  chain_state_load(d, c, S);
+  chain_state_load(d, c, S, D);
   // the slices' partial sums, added by all lanes in a fixed order (lane-strided, then the
   // wavefront tree, then wavefront after wavefront): up to max_slices loads that one lane would
   // wait for one after the other
@@ -1807,34 +1843,34 @@ __global__ void split_ends_kernel(Dev d_by_value, uint32_t Tcur, uint32_t slices
   }
   const double slices_sum = block_sum(part, S);
   if (threadIdx.x == 0) {
-    S.Tcur = Tcur;
-    S.accept = 0;
-    S.op = OP_END;
+    D.Tcur = Tcur;
+    D.accept = 0;
+    D.op = OP_END;
     if (finish) {
-      ctl_to_shared(d, c, S, Tcur);
-      S.n_upd = 1;
-      if (S.op != OP_END) {
+      ctl_to_shared(d, c, D, Tcur);
+      D.n_upd = 1;
+      if (D.op != OP_END) {
         const double r = slices_sum;
-        S.n_units = d.ctl[c].total;
-        if (S.op == OP_EVAL_STATE) S.n_state = 1;
+        D.n_units = d.ctl[c].total;
+        if (D.op == OP_EVAL_STATE) D.n_state = 1;
         SerialRng rng{S.rng};
-        const bool accept = driver_finish_update(d, c, S, rng, r);
-        S.accept = accept ? 1 : 0;
-        if (accept) S.n_acc = 1;
-        S.pending = PEND_NONE;
+        const bool accept = driver_finish_update(d, c, D, rng, r);
+        D.accept = accept ? 1 : 0;
+        if (accept) D.n_acc = 1;
+        D.pending = PEND_NONE;
       }
     }
   }
   __syncthreads();
   if (threadIdx.x == 0) d.ctl[c].move_from = 0;
-  if (S.op == OP_EVAL_STATE && S.accept) {
-    const Pose q{S.q[0], S.q[1], S.q[2]};
+  if (D.op == OP_EVAL_STATE && D.accept) {
+    const Pose q{D.q[0], D.q[1], D.q[2]};
     if (defer_commit) {  // split_commit_kernel moves the poses, with many workgroups
-      const PoseMove m = pose_move_of(d, c, S.idx, q);
-      move_parent_poses(d, c, S.idx, S.nf, m);  // few enough for this workgroup
+      const PoseMove m = pose_move_of(d, c, D.idx, q);
+      move_parent_poses(d, c, D.idx, D.nf, m);  // few enough for this workgroup
       if (threadIdx.x == 0) {
         ChainCtl& k = d.ctl[c];
-        k.move_from = S.idx + 1;
+        k.move_from = D.idx + 1;
         k.move_pivot[0] = m.pivot_x;
         k.move_pivot[1] = m.pivot_y;
         k.move_to[0] = m.to_x;
@@ -1844,25 +1880,25 @@ __global__ void split_ends_kernel(Dev d_by_value, uint32_t Tcur, uint32_t slices
         k.move_dth = m.dth;
       }
     } else {
-      commit_state_edge(d, c, S.idx, q, Tcur, S.nf);
+      commit_state_edge(d, c, D.idx, q, Tcur, D.nf);
     }
     __syncthreads();  // the old relative angle has been read
     if (threadIdx.x == 0) {
-      const size_t ri = size_t(c) * d.Tcap + S.idx;
+      const size_t ri = size_t(c) * d.Tcap + D.idx;
       d.relx[ri] = q.x;
       d.rely[ri] = q.y;
       d.relth[ri] = q.th;
-      S.n_moved = Tcur - S.idx;
+      D.n_moved = Tcur - D.idx;
     }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    S.op = OP_END;
+    D.op = OP_END;
     SerialRng rng{S.rng};
-    if (begin && !S.failed && !d.errflag[c] && !driver_begin_update(d, c, S, rng)) S.op = OP_END;
-    shared_to_ctl(d, c, S);
+    if (begin && !D.failed && !d.errflag[c] && !driver_begin_update(d, c, S, D, rng)) D.op = OP_END;
+    shared_to_ctl(d, c, D);
   }
-  chain_state_store(d, c, S);
+  chain_state_store(d, c, S, D);
 }
 
 // The pose table of the chains whose state-edge proposal split_ends_kernel has just accepted

@@ -347,7 +347,11 @@ constexpr size_t kStaticScratchBytes = (size_t(kScanTargetGroups) + kStaticScanC
 static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
 
 constexpr int kMaxDevices = 64;
-constexpr uint32_t kSoloMaxChains = 256;  // chains (= CUs) up to which a launch takes advance_kernel's SOLO variant
+constexpr uint32_t kSoloMaxChains = 256;  // chains (= CUs) up to which a handle's default workgroup is 256 lanes wide
+// advance_kernel's SOLO variant (serial program compiled in, 256 registers: one wavefront per SIMD) is taken
+// by launches of at most this many wavefronts, i.e. when every wavefront has a SIMD to itself anyway and the
+// serial program is the launch's critical path: 256 chains of 256 lanes, 1024 chains of 64
+constexpr uint32_t kSoloMaxWaves = 1024;
 std::mutex g_static_scratch_mutex;
 void* g_static_scratch[kMaxDevices] = {};
 
@@ -533,12 +537,15 @@ const char* mcmcgpu_last_error(mcmcgpu_handle h) { return h ? h->error.c_str() :
 int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out) {
   if (!cfg || !out) return fail(nullptr, MCMCGPU_ERR_ARGUMENT, "null argument");
   if (cfg->max_chains == 0) return fail(nullptr, MCMCGPU_ERR_ARGUMENT, "max_chains must be positive");
-  // default width: 256 lanes; many chains on data with at most 16 readings per lane of such a workgroup
-  // (Plaza has 3 500 in all) keep 128 busier and pay less per barrier -- but not the few chains whose
-  // serial part is compiled in (Plaza1, one chain: 28 200 cycles per update with 256 lanes, 29 500 with 128)
+  // default width: 256 lanes.  Many chains on sparse data (at most 32 768 readings in all, so a proposal
+  // touches a few dozen to a few thousand) take ONE wavefront per chain: such an update is its serial part,
+  // four chains per CU then run it on a SIMD each and no barrier joins wavefronts (commit-heavy benchmark,
+  // 1024 chains x 10 000 poses, 52 readings per proposal: 5.3e9 units/s against 3.2e9 with 128 or 256 lanes).
+  // Few chains keep 256 lanes: their stream is spread over the CU they have to themselves (Plaza1, one
+  // chain: 28 200 cycles per update with 256 lanes, 29 500 with 128).
   const uint32_t nthr = cfg->threads_per_chain
                             ? cfg->threads_per_chain
-                            : (cfg->max_observations <= 4096 && cfg->max_chains > kSoloMaxChains ? 128 : 256);
+                            : (cfg->max_observations <= 32768 && cfg->max_chains > kSoloMaxChains ? 64 : 256);
   if (nthr < 64 || nthr > 1024 || !is_pow2(nthr))
     return fail(nullptr, MCMCGPU_ERR_ARGUMENT, "threads_per_chain must be a power of two in [64, 1024]");
   if (cfg->serial_program > 2) return fail(nullptr, MCMCGPU_ERR_ARGUMENT, "serial_program must be 0, 1 or 2");
@@ -1025,7 +1032,8 @@ int mcmcgpu_advance(mcmcgpu_handle h, uint32_t upto, uint32_t steps_per_timestep
   const size_t dyn_lds = (size_t(tops.sw_n) + tops.fw_n) * sizeof(double);
   // one kernel per observation model; few chains take the variant with the serial program compiled in
   const bool solo = h->nthreads <= 256 &&  // that variant is built for at most 256 lanes
-                    (h->cfg.serial_program == 2 || (h->cfg.serial_program == 0 && h->chains <= kSoloMaxChains));
+                    (h->cfg.serial_program == 2 ||
+                     (h->cfg.serial_program == 0 && uint64_t(h->chains) * (h->nthreads / 64) <= kSoloMaxWaves));
   auto* const kernel = h->cfg.range_bearing ? (solo ? advance_kernel<true, true> : advance_kernel<true, false>)
                                             : (solo ? advance_kernel<false, true> : advance_kernel<false, false>);
   if (dyn_lds > 48 * 1024 && h->advance_lds_raised.insert(reinterpret_cast<const void*>(kernel)).second)
