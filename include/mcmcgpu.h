@@ -69,7 +69,10 @@ typedef struct mcmcgpu_config {
    * lanes, 1024 chains of 64 -- so that every wavefront has a SIMD to itself and the serial part is
    * the launch's critical path; a called function
    * otherwise, which keeps the registers of the loop over readings free); 1 = always called;
-   * 2 = compiled in whenever the workgroup has at most 256 lanes.  Results do not depend on it. */
+   * 2 = compiled in whenever the workgroup has at most 256 lanes; 3 = compiled in, and the first
+   * wavefront selects and proposes the next update while the others evaluate the current one
+   * (workgroups of 128 or 256 lanes; what 0 chooses for few chains on data of at most 32 768
+   * readings, where an update's serial part outlasts its evaluation).  Results do not depend on it. */
   uint32_t serial_program;
 } mcmcgpu_config;
 

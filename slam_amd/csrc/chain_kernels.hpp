@@ -159,7 +159,7 @@ struct ChainCtl {
 };
 
 constexpr int kMaxSeg = 256;   // landmark segments evaluated per pass
-constexpr int kActCap = 1024;  // landmarks examined per round (blockDim.x divides it)
+constexpr int kActCap = 1024;  // most landmarks examined per round
 constexpr int kMaxWaves = 16;
 constexpr uint32_t kMaxRetry = 1u << 16;
 
@@ -233,6 +233,13 @@ __device__ unsigned long long g_phase_cycles[16];
 // by one lane it lives in the chain's LDS block (Shared::drv); when it is compiled into the kernel and run
 // by a whole wavefront on the same data (advance_kernel's SOLO variant) it is a local object of the kernel,
 // i.e. registers: a lone wavefront waits out every LDS round trip, and the program reads these all the time.
+// One update as selection and proposal leave it for the evaluation (mcmc_slam.hpp:339-382).
+struct Request {
+  int op;
+  uint32_t idx;
+  double q[3];
+  double new_pll, old_pll;
+};
 struct DriverState {
   int stage;
   uint32_t tn, upto, arr, arr_end, steps_left, steps_per_ts, end_left, end_done, end_inflight;
@@ -256,6 +263,19 @@ struct DriverState {
   uint32_t idx;
   double q[3];
   int accept;
+  // the NEXT update, selected and proposed ahead of time on the assumption that the update in flight is
+  // rejected (advance_kernel's SPEC variant); driver_begin_update takes it instead of drawing
+  int spec_ready;
+  Request spec;
+};
+
+// A request as the SPEC variant's first wavefront posts it for the others.
+struct Posted {
+  int op;
+  uint32_t idx;
+  double q[3];
+  uint32_t Tcur, nf;
+  uint32_t join;  // with a commit: every wavefront meets again when the pose table is moved
 };
 
 struct Shared {
@@ -277,6 +297,11 @@ struct Shared {
 #endif
   uint32_t wcount[kMaxWaves];
   double red[kMaxWaves];
+  // advance_kernel's SPEC variant: the barrier of the wavefronts after the first (TailWaves), and what they
+  // hand the first one when an evaluation is done: its number, its sum and the readings it went through
+  uint32_t tail_arrivals, eval_arrived;
+  unsigned long long eval_units;
+  Posted post[2];
 };
 
 // Separately compiled pieces (see advance_kernel) take the kernel-argument block and the chain's
@@ -332,36 +357,102 @@ MG_DEV wt::Cached landmark_tree(const Dev& d, uint32_t c, const DriverState& D) 
 // ---------------------------------------------------------------------------
 // workgroup helpers
 
-MG_DEV uint32_t block_scan_u32(uint32_t v, Shared& S, uint32_t& total) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+// The lanes that run the data-parallel parts of an update together: the whole workgroup, or -- while the
+// first wavefront runs ahead with the serial program (advance_kernel's SPEC variant) -- the wavefronts
+// after the first, which then meet at a barrier of their own in LDS (the hardware barrier counts every
+// wavefront of the workgroup).
+struct WholeBlock {
+  MG_DEV uint32_t tid() const { return threadIdx.x; }
+  MG_DEV uint32_t size() const { return blockDim.x; }
+  MG_DEV void sync() { __syncthreads(); }
+  MG_DEV double sum(double v, struct Shared& S);  // over the team, in a fixed order; valid in its first lane
+};
+struct TailWaves {
+  uint32_t* arrivals;   // in LDS, zero at launch: wavefronts that have arrived at any barrier so far
+  uint32_t passed = 0;  // barriers this wavefront has passed
+  MG_DEV explicit TailWaves(uint32_t* counter) : arrivals(counter) {}
+  MG_DEV uint32_t tid() const { return threadIdx.x - 64u; }
+  MG_DEV uint32_t size() const { return blockDim.x - 64u; }
+  // Leaves every wavefront's sum in S.red for the first wavefront of the workgroup to add up (in the order
+  // WholeBlock::sum adds them) and counts the wavefront in S.eval_arrived; returns nothing of use.
+  MG_DEV double sum(double v, struct Shared& S);
+  MG_DEV void sync() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t nw = (blockDim.x >> 6) - 1u;
+    ++passed;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (nw > 1u) {
+      if ((threadIdx.x & 63u) == 0) __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const uint32_t want = passed * nw;
+      // every wavefront of a workgroup is resident, so the ones still to arrive make progress
+      while (int32_t(__hip_atomic_load(arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - want) < 0) {
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#endif
+  }
+};
+
+template <class Team>
+MG_DEV uint32_t block_scan_u32(uint32_t v, Shared& S, uint32_t& total, Team& tm) {
+  const int lane = tm.tid() & 63, wave = tm.tid() >> 6, nwaves = tm.size() >> 6;
 #pragma unroll
   for (int dd = 1; dd < 64; dd <<= 1) {
     const uint32_t o = __shfl_up(v, dd);
     if (lane >= dd) v += o;
   }
   if (lane == 63) S.wcount[wave] = v;
-  __syncthreads();
+  tm.sync();
   uint32_t before = 0, all = 0;
   for (int w = 0; w < nwaves; ++w) {
     if (w == wave) before = all;
     all += S.wcount[w];
   }
   total = all;
-  __syncthreads();
+  tm.sync();
   return v + before;  // inclusive
 }
+MG_DEV uint32_t block_scan_u32(uint32_t v, Shared& S, uint32_t& total) {
+  WholeBlock tm;
+  return block_scan_u32(v, S, total, tm);
+}
 
-// Sum over the workgroup in a fixed order; the result is valid in lane 0.
-MG_DEV double block_sum(double v, Shared& S) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+// Sum over the team in a fixed order; the result is valid in its first lane.
+template <class Team>
+MG_DEV double block_sum(double v, Shared& S, Team& tm) {
+  const int lane = tm.tid() & 63, wave = tm.tid() >> 6, nwaves = tm.size() >> 6;
 #pragma unroll
   for (int dd = 32; dd > 0; dd >>= 1) v += __shfl_down(v, dd);
   if (lane == 0) S.red[wave] = v;
-  __syncthreads();
+  tm.sync();
   double r = 0.0;
-  if (threadIdx.x == 0)
+  if (tm.tid() == 0)
     for (int w = 0; w < nwaves; ++w) r += S.red[w];
-  __syncthreads();
+  tm.sync();
+  return r;
+}
+MG_DEV double block_sum(double v, Shared& S) {
+  WholeBlock tm;
+  return block_sum(v, S, tm);
+}
+MG_DEV double WholeBlock::sum(double v, Shared& S) { return block_sum(v, S, *this); }
+MG_DEV double TailWaves::sum(double v, Shared& S) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+  for (int dd = 32; dd > 0; dd >>= 1) v += __shfl_down(v, dd);
+  if ((threadIdx.x & 63u) == 0) {
+    S.red[tid() >> 6] = v;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __hip_atomic_fetch_add(&S.eval_arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+#endif
+  return 0.0;
+}
+// What TailWaves::sum left, added up by the reader.
+MG_DEV double tail_waves_sum(const Shared& S) {
+  double r = 0.0;
+  const int nwaves = int(blockDim.x >> 6) - 1;
+  for (int w = 0; w < nwaves; ++w) r += S.red[w];
   return r;
 }
 
@@ -432,7 +523,7 @@ struct RatioStream {
   const Dev& d;
   const Shared& S;
   const PoseXY* __restrict__ pxy;
-  const uint32_t total, stride;
+  const uint32_t total, stride, first;
   const double half_isd2;
   uint32_t cur = 0, seg_end, seg_base;
   double acc = 0.0;
@@ -440,8 +531,9 @@ struct RatioStream {
   uint32_t seg_tbase;
 #endif
 
-  MG_DEV RatioStream(const Dev& d_, uint32_t c, const Shared& S_, uint32_t nseg)
-      : d(d_), S(S_), pxy(d_.pxy + size_t(c) * (d_.Tcap + 1)), total(S_.segpre[nseg]), stride(blockDim.x),
+  // the team's lane `first_` of `stride_`
+  MG_DEV RatioStream(const Dev& d_, uint32_t c, const Shared& S_, uint32_t nseg, uint32_t first_, uint32_t stride_)
+      : d(d_), S(S_), pxy(d_.pxy + size_t(c) * (d_.Tcap + 1)), total(S_.segpre[nseg]), stride(stride_), first(first_),
         half_isd2(0.5 * d_.usig_inv * d_.usig_inv), seg_end(S_.segcur[0].x), seg_base(S_.segcur[0].y) {
 #ifdef MG_DIAG_RUN_RECORDS
     seg_tbase = S_.segt[0];
@@ -531,7 +623,6 @@ struct RatioStream {
     const uint32_t group = U * stride;
     Recs r0, r1;
     Poses p0, p1;
-    const uint32_t first = threadIdx.x;
     request_records(first, r0);
     request_records(first + group, r1);
     request_poses(first, r0, p0);
@@ -568,14 +659,14 @@ struct BearingStream {
   const Shared& S;
   const PoseXY* __restrict__ pxy;
   const double* __restrict__ pth;
-  const uint32_t total, stride;
+  const uint32_t total, stride, first;
   const double half_isd2, half_ibsd2;
   uint32_t cur = 0, seg_end, seg_base;
   double acc = 0.0;
 
-  MG_DEV BearingStream(const Dev& d_, uint32_t c, const Shared& S_, uint32_t nseg)
+  MG_DEV BearingStream(const Dev& d_, uint32_t c, const Shared& S_, uint32_t nseg, uint32_t first_, uint32_t stride_)
       : d(d_), S(S_), pxy(d_.pxy + size_t(c) * (d_.Tcap + 1)), pth(d_.pth + size_t(c) * (d_.Tcap + 1)),
-        total(S_.segpre[nseg]), stride(blockDim.x), half_isd2(0.5 * d_.usig_inv * d_.usig_inv),
+        total(S_.segpre[nseg]), stride(stride_), first(first_), half_isd2(0.5 * d_.usig_inv * d_.usig_inv),
         half_ibsd2(0.5 * d_.ubsig_inv * d_.ubsig_inv), seg_end(S_.segpre[1]), seg_base(S_.seglo[0]) {}
 
   MG_DEV void request_records(uint32_t i0, Recs& r) {
@@ -649,7 +740,6 @@ struct BearingStream {
     const uint32_t group = U * stride;
     Recs r0, r1;
     Poses p0, p1;
-    const uint32_t first = threadIdx.x;
     request_records(first, r0);
     request_records(first + group, r1);
     request_poses(first, r0, p0);
@@ -667,22 +757,22 @@ struct BearingStream {
 // range-only stream 5 %: live values of the caller saved around a call it never makes.)
 // The bearing stream is once more a piece inside its evaluation piece: inlined there, next to the
 // landmark set-up, it spills (1.0e11 instead of 1.2e11 units/s).
-MG_PIECE double piece_bearing_stream(DevArgs dp, SharedLds sp, uint32_t c, uint32_t nseg) {
+MG_PIECE double piece_bearing_stream(DevArgs dp, SharedLds sp, uint32_t c, uint32_t nseg, uint32_t first, uint32_t stride) {
   const Dev& d = *(const Dev*)dp;
   const Shared& S = *(const Shared*)sp;
   // one sigma for all ranges and one for all bearings (what the reference's model holds,
   // range_bearing_model.hpp:21-117) -> no per-reading loads of them
-  if (d.usig_inv > 0.0 && d.ubsig_inv > 0.0) return BearingStream<true>(d, c, S, nseg).run();
-  return BearingStream<false>(d, c, S, nseg).run();
+  if (d.usig_inv > 0.0 && d.ubsig_inv > 0.0) return BearingStream<true>(d, c, S, nseg, first, stride).run();
+  return BearingStream<false>(d, c, S, nseg, first, stride).run();
 }
 
 template <bool RB>
-MG_DEV double eval_ratio(const Dev& d, uint32_t c, const Shared& S, uint32_t nseg) {
+MG_DEV double eval_ratio(const Dev& d, uint32_t c, const Shared& S, uint32_t nseg, uint32_t first, uint32_t stride) {
   // `d` is the argument block itself here (see MG_KERNEL_DEV), S the chain's LDS block
-  if (RB) return piece_bearing_stream((DevArgs)&d, (SharedLds)&S, c, nseg);
+  if (RB) return piece_bearing_stream((DevArgs)&d, (SharedLds)&S, c, nseg, first, stride);
   // every reading has the same sigma (what the reference's builder produces) -> no per-reading load of it
-  if (d.usig_inv > 0.0) return RatioStream<true>(d, c, S, nseg).run();
-  return RatioStream<false>(d, c, S, nseg).run();
+  if (d.usig_inv > 0.0) return RatioStream<true>(d, c, S, nseg, first, stride).run();
+  return RatioStream<false>(d, c, S, nseg, first, stride).run();
 }
 
 // ---------------------------------------------------------------------------
@@ -792,11 +882,11 @@ MG_DEV double full_ll_segments_rb(const Dev& d, uint32_t c, const Shared& S, uin
 
 // Landmark edge (mcmc_slam.hpp:468-474): every reading of landmark f seen so
 // far, old estimate against `e_new`, both relative to the parent pose.
-template <bool RB>
+template <bool RB, class Team>
 MG_DEV double eval_feature_edge(const Dev& d, uint32_t c, Shared& S, uint32_t f, const Vec2& e_new,
-                                unsigned long long& units) {
+                                unsigned long long& units, Team& tm) {
   const size_t fi = size_t(c) * d.Fcap + f;
-  if (threadIdx.x == 0) {
+  if (tm.tid() == 0) {
     const Frame Pp = parent_frame(d, fi);
     const Vec2 wo = act(Pp, Vec2{d.fex[fi], d.fey[fi]});
     const Vec2 wn = act(Pp, e_new);
@@ -809,10 +899,16 @@ MG_DEV double eval_feature_edge(const Dev& d, uint32_t c, Shared& S, uint32_t f,
     S.segw[0][2] = wn.x;
     S.segw[0][3] = wn.y;
   }
-  __syncthreads();
+  tm.sync();
   units += S.segpre[1];
-  const double acc = eval_ratio<RB>(d, c, S, 1);
-  return block_sum(acc, S);
+  const double acc = eval_ratio<RB>(d, c, S, 1, tm.tid(), tm.size());
+  return tm.sum(acc, S);
+}
+template <bool RB>
+MG_DEV double eval_feature_edge(const Dev& d, uint32_t c, Shared& S, uint32_t f, const Vec2& e_new,
+                                unsigned long long& units) {
+  WholeBlock tm;
+  return eval_feature_edge<RB>(d, c, S, f, e_new, units, tm);
 }
 
 // upper_bound of timestep t in the time-sorted readings [lo, hi) of landmark f.  Two tables cut the
@@ -898,10 +994,10 @@ MG_DEV ProposalFrames proposal_frames(const Pose& Pt, const Pose& Pt1, const Pos
 // readings taken up to t are affected; otherwise the landmark stays and the
 // readings after t are affected.  Either way the affected readings compare
 // |w_new - t_s| with |w_old - t_s| on the UNCHANGED pose table.
-template <bool RB>
+template <bool RB, class Team>
 MG_DEV double eval_state_edge(const Dev& d, uint32_t c, Shared& S, uint32_t t, const Pose& q, uint32_t nf,
-                              unsigned long long& units) {
-  const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+                              unsigned long long& units, Team& tm) {
+  const uint32_t tid = tm.tid(), nthr = tm.size();
   const uint32_t segcap = nthr < uint32_t(kMaxSeg) ? nthr : uint32_t(kMaxSeg);
   const ProposalFrames fr = proposal_frames(world_pose(d, c, t), world_pose(d, c, t + 1), q);
   const size_t fbase = size_t(c) * d.Fcap;
@@ -945,35 +1041,63 @@ MG_DEV double eval_state_edge(const Dev& d, uint32_t c, Shared& S, uint32_t t, c
   };
   auto stream = [&](uint32_t len, uint32_t nseg) {
     uint32_t total;
-    const uint32_t incl = block_scan_u32(len, S, total);
+    const uint32_t incl = block_scan_u32(len, S, total, tm);
     if (tid < nseg) {
       S.segpre[tid + 1] = incl;
       S.segcur[tid] = make_uint2(incl, S.seglo[tid] - (incl - len));  // this lane wrote seglo[tid] itself
     }
     if (tid == 0) S.segpre[0] = 0;
-    __syncthreads();
+    tm.sync();
     units += total;
     MG_STAMP(tc0);
     MG_PHASE_ADD(S, 1, tab, tc0);
     // C: stream the affected readings
-    acc += eval_ratio<RB>(d, c, S, nseg);
-    __syncthreads();
+    acc += eval_ratio<RB>(d, c, S, nseg, tid, nthr);
+    tm.sync();
     MG_STAMP(tc1);
     MG_PHASE_ADD(S, 2, tc0, tc1);
 #ifdef MG_PHASE_TIMING
     tab = tc1;
 #endif
   };
+  if (nf <= 64) {
+    // a wavefront's worth of landmarks: the team's first wavefront prepares them all, every landmark a
+    // segment (those without affected readings an empty one), with the prefix sums taken inside the
+    // wavefront -- one barrier instead of three
+    if (tid < 64) {
+      uint32_t len = 0;
+      if (tid < nf) len = prepare(tid, d.ffirst[tid] <= t && t < d.flast[fbase + tid]);
+      uint32_t incl = len;
+#pragma unroll
+      for (int dd = 1; dd < 64; dd <<= 1) {
+        const uint32_t o = __shfl_up(incl, dd);
+        if (tid >= uint32_t(dd)) incl += o;
+      }
+      if (tid < nf) {
+        S.segpre[tid + 1] = incl;
+        S.segcur[tid] = make_uint2(incl, S.seglo[tid] - (incl - len));
+      }
+      if (tid == 0) S.segpre[0] = 0;
+    }
+    tm.sync();
+    units += S.segpre[nf];
+    MG_STAMP(tc0);
+    MG_PHASE_ADD(S, 1, tab, tc0);
+    acc += eval_ratio<RB>(d, c, S, nf, tid, nthr);
+    MG_STAMP(tc1);
+    MG_PHASE_ADD(S, 2, tc0, tc1);
+    return tm.sum(acc, S);
+  }
   if (nf <= segcap) {
     // few landmarks: every one is a segment, those without affected readings an empty one (the
     // readings come in the same order as below, so the sums are the same)
     uint32_t len = 0;
     if (tid < nf) len = prepare(tid, d.ffirst[tid] <= t && t < d.flast[fbase + tid]);
     stream(len, nf);
-    return block_sum(acc, S);
+    return tm.sum(acc, S);
   }
   const uint32_t per = uint32_t(kActCap) / nthr;  // landmarks examined per lane and round (1..16)
-  for (uint32_t f0 = 0; f0 < nf; f0 += uint32_t(kActCap)) {
+  for (uint32_t f0 = 0; f0 < nf; f0 += per * nthr) {  // (a team of 192 lanes examines 960 per round)
     // A: which landmarks have affected readings?  first <= t < last
     uint32_t flags = 0;
     for (uint32_t k = 0; k < per; ++k) {
@@ -985,10 +1109,10 @@ MG_DEV double eval_state_edge(const Dev& d, uint32_t c, Shared& S, uint32_t t, c
     }
     const uint32_t cnt = __popc(flags);
     uint32_t nact;
-    uint32_t at = block_scan_u32(cnt, S, nact) - cnt;
+    uint32_t at = block_scan_u32(cnt, S, nact, tm) - cnt;
     for (uint32_t k = 0; k < per; ++k)
       if ((flags >> k) & 1u) S.act[at++] = f0 + tid * per + k;
-    __syncthreads();
+    tm.sync();
     for (uint32_t a0 = 0; a0 < nact; a0 += segcap) {
       const uint32_t nseg = (nact - a0) < segcap ? (nact - a0) : segcap;
       uint32_t len = 0;
@@ -996,7 +1120,13 @@ MG_DEV double eval_state_edge(const Dev& d, uint32_t c, Shared& S, uint32_t t, c
       stream(len, nseg);
     }
   }
-  return block_sum(acc, S);
+  return tm.sum(acc, S);
+}
+template <bool RB>
+MG_DEV double eval_state_edge(const Dev& d, uint32_t c, Shared& S, uint32_t t, const Pose& q, uint32_t nf,
+                              unsigned long long& units) {
+  WholeBlock tm;
+  return eval_state_edge<RB>(d, c, S, t, q, nf, units, tm);
 }
 
 // Accepted state edge t <- q: P'[k] = P[k] (k <= t), D o P[k] (k > t) with
@@ -1047,9 +1177,10 @@ MG_DEV void move_poses(const Dev& d, size_t base, uint32_t first, uint32_t end, 
   for (; k < end; k += stride) move_pose(d, base + k, m);
 }
 // The copies of parent poses after edge t move exactly as their table entries do (all lanes).
-MG_DEV void move_parent_poses(const Dev& d, uint32_t c, uint32_t t, uint32_t nf, const PoseMove& m) {
+MG_DEV void move_parent_poses(const Dev& d, uint32_t c, uint32_t t, uint32_t nf, const PoseMove& m, uint32_t first,
+                              uint32_t stride) {
   const size_t fbase = size_t(c) * d.Fcap;
-  for (uint32_t f = threadIdx.x; f < nf; f += blockDim.x) {
+  for (uint32_t f = first; f < nf; f += stride) {
     const size_t fi = fbase + f;
     if (d.fpt[fi] > t) {
       const PoseXY p = moved(m, PoseXY{d.fpx[fi], d.fpy[fi]});
@@ -1064,12 +1195,20 @@ MG_DEV void move_parent_poses(const Dev& d, uint32_t c, uint32_t t, uint32_t nf,
     }
   }
 }
-MG_DEV void commit_state_edge(const Dev& d, uint32_t c, uint32_t t, const Pose& q, uint32_t Tcur, uint32_t nf) {
+MG_DEV void move_parent_poses(const Dev& d, uint32_t c, uint32_t t, uint32_t nf, const PoseMove& m) {
+  move_parent_poses(d, c, t, nf, m, threadIdx.x, blockDim.x);
+}
+template <class Team>
+MG_DEV void commit_state_edge(const Dev& d, uint32_t c, uint32_t t, const Pose& q, uint32_t Tcur, uint32_t nf, Team& tm) {
   const size_t base = size_t(c) * (d.Tcap + 1);
   const PoseMove m = pose_move_of(d, c, t, q);
-  __syncthreads();  // every lane holds the old pivot before anything is overwritten
-  move_poses(d, base, t + 1 + threadIdx.x, Tcur + 1, blockDim.x, m);
-  move_parent_poses(d, c, t, nf, m);
+  tm.sync();  // every lane holds the old pivot before anything is overwritten
+  move_poses(d, base, t + 1 + tm.tid(), Tcur + 1, tm.size(), m);
+  move_parent_poses(d, c, t, nf, m, tm.tid(), tm.size());
+}
+MG_DEV void commit_state_edge(const Dev& d, uint32_t c, uint32_t t, const Pose& q, uint32_t Tcur, uint32_t nf) {
+  WholeBlock tm;
+  commit_state_edge(d, c, t, q, Tcur, nf, tm);
 }
 
 // ---------------------------------------------------------------------------
@@ -1203,13 +1342,20 @@ MG_DEV uint32_t draw_index(const wt::Cached& tree, uint32_t n, double value) {
   return wt::search(tree, n, value);
 }
 
-template <class R>
-MG_DEV bool driver_begin_update(const Dev& d, uint32_t c, Shared& S, DriverState& D, R& rng) {
+// `watch()` is asked between the parts of the work whether to give up (a selection made ahead of time
+// whose premise has just turned out false); the plain call never gives up.
+struct NeverGiveUp {
+  MG_DEV bool operator()() { return false; }
+};
+enum BeginStatus : int { BEGIN_OK = 1, BEGIN_NOTHING = 0, BEGIN_FAILED = -1, BEGIN_GIVEN_UP = -2 };
+// Writes the update to `out` and touches nothing of D but the cached weight totals.
+template <class R, class Watch>
+MG_DEV int begin_update_core(const Dev& d, uint32_t c, Shared& S, DriverState& D, R& rng, Request& out, Watch& watch) {
   const wt::Cached sw = state_tree(d, c, D), fw = landmark_tree(d, c, D);
   MG_MARK_BEGIN();
   refresh_totals(d, c, D);
   const double Ws = D.Ws, Wf = D.Wf;
-  if (Ws == 0 && Wf == 0) return false;
+  if (Ws == 0 && Wf == 0) return BEGIN_NOTHING;
   uint32_t retry = 0;
   MG_MARK(S, 8);
   const double which = rng.uniform();
@@ -1219,11 +1365,9 @@ MG_DEV bool driver_begin_update(const Dev& d, uint32_t c, Shared& S, DriverState
     do {
       t = draw_index<R>(sw, D.Tcur, Ws * rng.uniform());
     } while (t >= D.Tcur && ++retry < kMaxRetry);
-    if (t >= D.Tcur) {
-      D.failed = 1;
-      return false;
-    }
+    if (t >= D.Tcur) return BEGIN_FAILED;
     MG_MARK(S, 10);
+    if (watch()) return BEGIN_GIVEN_UP;
     double mu[3], sd[3], v[3], ld;
     load_control(d, t, mu, sd, ld);
     // the current relative pose's log density is kept from when that pose was set
@@ -1231,39 +1375,64 @@ MG_DEV bool driver_begin_update(const Dev& d, uint32_t c, Shared& S, DriverState
     for (int i = 0; i < 3; ++i) v[i] = rng.normal();
     for (int i = 0; i < 3; ++i) v[i] = v[i] * sd[i] + mu[i];
     MG_MARK(S, 11);
+    if (watch()) return BEGIN_GIVEN_UP;
     const Pose q = control_inv_observe(v);
     MG_MARK(S, 12);
-    D.new_pll = control_log_pdf(mu, sd, ld, q);
-    D.old_pll = old_pll;
+    out.new_pll = control_log_pdf(mu, sd, ld, q);
+    out.old_pll = old_pll;
     MG_MARK(S, 13);
-    D.op = OP_EVAL_STATE;
-    D.idx = t;
-    D.q[0] = q.x;
-    D.q[1] = q.y;
-    D.q[2] = q.th;
+    out.op = OP_EVAL_STATE;
+    out.idx = t;
+    out.q[0] = q.x;
+    out.q[1] = q.y;
+    out.q[2] = q.th;
   } else {
     uint32_t f;
     do {
       f = draw_index<R>(fw, D.nf, Wf * rng.uniform());
     } while (f >= D.nf && ++retry < kMaxRetry);
-    if (f >= D.nf) {
-      D.failed = 1;
-      return false;
-    }
+    if (f >= D.nf) return BEGIN_FAILED;
+    if (watch()) return BEGIN_GIVEN_UP;
     const size_t fi = size_t(c) * d.Fcap + f;
     const Reading m = parent_reading(d, fi);
     const Vec2 q = propose_landmark(d, rng, m);
-    D.new_pll = reading_proposal_log_pdf(m, q);
-    D.old_pll = reading_proposal_log_pdf(m, Vec2{d.fex[fi], d.fey[fi]});
-    D.op = OP_EVAL_FEATURE;
-    D.idx = f;
-    D.q[0] = q.x;
-    D.q[1] = q.y;
-    D.q[2] = 0.0;
+    out.new_pll = reading_proposal_log_pdf(m, q);
+    out.old_pll = reading_proposal_log_pdf(m, Vec2{d.fex[fi], d.fey[fi]});
+    out.op = OP_EVAL_FEATURE;
+    out.idx = f;
+    out.q[0] = q.x;
+    out.q[1] = q.y;
+    out.q[2] = 0.0;
     MG_MARK(S, 14);
   }
+  return BEGIN_OK;
+}
+
+MG_DEV void post_request(DriverState& D, const Request& rq) {
+  D.op = rq.op;
+  D.idx = rq.idx;
+  D.q[0] = rq.q[0];
+  D.q[1] = rq.q[1];
+  D.q[2] = rq.q[2];
+  D.new_pll = rq.new_pll;
+  D.old_pll = rq.old_pll;
   D.pending = PEND_UPDATE;
   D.use_weight = 1;
+}
+
+template <class R>
+MG_DEV bool driver_begin_update(const Dev& d, uint32_t c, Shared& S, DriverState& D, R& rng) {
+  if (D.spec_ready) {  // selected and proposed while the last update was evaluated, and that one was rejected
+    D.spec_ready = 0;
+    post_request(D, D.spec);
+    return true;
+  }
+  Request rq;
+  NeverGiveUp never;
+  const int st = begin_update_core(d, c, S, D, rng, rq, never);
+  if (st == BEGIN_FAILED) D.failed = 1;
+  if (st != BEGIN_OK) return false;
+  post_request(D, rq);
   return true;
 }
 
@@ -1331,6 +1500,75 @@ MG_DEV bool driver_finish_update(const Dev& d, uint32_t c, DriverState& D, R& rn
   }
   write_trace(d, c, D, is_state ? 0 : 1, D.idx, D.q, log_ratio, accept ? 1 : 0);
   return accept;
+}
+
+// driver_finish_update in three parts, for a caller that has something to do between them (advance_kernel's
+// SPEC variant): what does not need the evaluation's result -- the two weights, the normaliser, the
+// uniform of the accept test (:389-401, :408: nothing else draws between the proposal and that uniform);
+// the decision once the result is there; and what the decision changes.  Same operations on the same
+// numbers as the one-piece form.
+struct FinishPrepared {
+  double new_weight;
+  double log_weight_change;  // new_log_weight - old_log_weight
+  double bar_factor;         // normaliser x the accept test's uniform
+};
+template <class R>
+MG_DEV FinishPrepared finish_prepare(const Dev& d, uint32_t c, DriverState& D, R& rng) {
+  const bool is_state = (D.op == OP_EVAL_STATE);
+  const double dim = is_state ? 3.0 : 2.0;
+  const double new_log_weight = log(dim) - D.new_pll / dim;
+  const double old_log_weight = log(dim) - D.old_pll / dim;
+  double new_weight, old_weight;
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (R::kWave) {
+    const double e = exp((threadIdx.x & 63u) == 1 ? old_log_weight : new_log_weight);
+    new_weight = wt::readlane_f64(e, 0);
+    old_weight = wt::readlane_f64(e, 1);
+  } else
+#endif
+  {
+    new_weight = exp(new_log_weight);
+    old_weight = D.use_weight ? exp(old_log_weight) : 0.0;
+  }
+  double normaliser = 1.0;
+  if (D.use_weight) {
+    refresh_totals(d, c, D);
+    const double weight_sum = D.Ws + D.Wf;
+    normaliser += (new_weight - old_weight) / weight_sum;
+  }
+  return FinishPrepared{new_weight, new_log_weight - old_log_weight, normaliser * rng.uniform()};
+}
+MG_DEV bool finish_decide(const DriverState& D, const FinishPrepared& pre, double obs_ratio) {
+  const bool is_state = (D.op == OP_EVAL_STATE);
+  const double proposal_log_ratio = D.new_pll - D.old_pll;
+  const double tempered = is_state ? (D.new_pll - D.old_pll) + D.beta * obs_ratio : D.beta * obs_ratio;
+  double accept_log_ratio = tempered - proposal_log_ratio;
+  if (D.use_weight) accept_log_ratio += pre.log_weight_change;
+#ifdef MG_DIAG_REJECT_ALL
+  return (pre.bar_factor < exp(accept_log_ratio)) && false;
+#else
+  return pre.bar_factor < exp(accept_log_ratio);
+#endif
+}
+MG_DEV void finish_apply(const Dev& d, uint32_t c, DriverState& D, const FinishPrepared& pre, double obs_ratio,
+                         bool accept) {
+  const bool is_state = (D.op == OP_EVAL_STATE);
+  const double log_ratio = is_state ? (D.new_pll - D.old_pll) + obs_ratio : obs_ratio;
+  if (accept) {
+    if (is_state) {
+      D.llc += D.new_pll - D.old_pll;
+      d.clp[size_t(c) * d.Tcap + D.idx] = D.new_pll;
+      wt::set(state_tree(d, c, D), D.Tcur, D.idx, pre.new_weight);
+    } else {
+      const size_t fi = size_t(c) * d.Fcap + D.idx;
+      d.fex[fi] = D.q[0];
+      d.fey[fi] = D.q[1];
+      wt::set(landmark_tree(d, c, D), D.nf, D.idx, pre.new_weight);
+    }
+    D.w_dirty = 1;
+    D.ll += log_ratio;
+  }
+  write_trace(d, c, D, is_state ? 0 : 1, D.idx, D.q, log_ratio, accept ? 1 : 0);
 }
 
 // One arrival during growth (mcmc_slam.hpp:283-331).  Returns true when a
@@ -1517,6 +1755,7 @@ MG_DEV void chain_state_load(const Dev& d, uint32_t c, Shared& S, DriverState& D
     D.sw_top = D.fw_top = 0;
     D.sw_shift = D.fw_shift = 0;
     D.pending = PEND_NONE;
+    D.spec_ready = 0;
   }
 }
 MG_DEV void chain_state_store(const Dev& d, uint32_t c, Shared& S, const DriverState& D) {
@@ -1553,14 +1792,14 @@ MG_DEV void chain_state_store(const Dev& d, uint32_t c, Shared& S, const DriverS
 // registers in every lane at every proposal -- about 100 KB each way per proposal, an eighth of
 // the kernel's memory traffic -- while the serial pieces, called by one lane, save next to nothing.
 // `units`: readings the evaluation went through (the same number in every lane).
-template <bool RB>
+template <bool RB, class Team>
 MG_DEV double inline_eval(DevArgs dp, SharedLds sp, uint32_t c, int op, uint32_t idx, double qx, double qy,
-                          double qth, uint32_t nf, unsigned long long& units) {
+                          double qth, uint32_t nf, unsigned long long& units, Team& tm) {
   const Dev& d = *(const Dev*)dp;
   Shared& S = *(Shared*)sp;
   units = 0;
-  if (op == OP_EVAL_STATE) return eval_state_edge<RB>(d, c, S, idx, Pose{qx, qy, qth}, nf, units);
-  return eval_feature_edge<RB>(d, c, S, idx, Vec2{qx, qy}, units);
+  if (op == OP_EVAL_STATE) return eval_state_edge<RB>(d, c, S, idx, Pose{qx, qy, qth}, nf, units, tm);
+  return eval_feature_edge<RB>(d, c, S, idx, Vec2{qx, qy}, units, tm);
 }
 
 // Lane 0's serial program between two requests to the workgroup, as ONE call: the end of the update
@@ -1641,11 +1880,12 @@ MG_DEV void step_body_wave(DevArgs dp, SharedLds sp, uint32_t c, double r, WaveR
 MG_PIECE void piece_step(DevArgs dp, SharedLds sp, uint32_t c, double r) { step_body(dp, sp, c, r); }
 
 // The pose table behind an accepted state edge and the edge's new relative pose (all lanes).
+template <class Team>
 MG_DEV void commit_body(DevArgs dp, uint32_t c, uint32_t idx, double qx, double qy, double qth, uint32_t Tcur,
-                        uint32_t nf) {
+                        uint32_t nf, Team& tm) {
   const Dev& d = *(const Dev*)dp;
-  commit_state_edge(d, c, idx, Pose{qx, qy, qth}, Tcur, nf);
-  if (threadIdx.x == 0) {
+  commit_state_edge(d, c, idx, Pose{qx, qy, qth}, Tcur, nf, tm);
+  if (tm.tid() == 0) {
     const size_t ri = size_t(c) * d.Tcap + idx;
     d.relx[ri] = qx;
     d.rely[ri] = qy;
@@ -1654,8 +1894,198 @@ MG_DEV void commit_body(DevArgs dp, uint32_t c, uint32_t idx, double qx, double 
 }
 MG_PIECE void piece_commit(DevArgs dp, uint32_t c, uint32_t idx, double qx, double qy, double qth, uint32_t Tcur,
                            uint32_t nf) {
-  commit_body(dp, c, idx, qx, qy, qth, Tcur, nf);
+  WholeBlock tm;
+  commit_body(dp, c, idx, qx, qy, qth, Tcur, nf, tm);
 }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// The first wavefront's view of the evaluation that runs beside it (advance_ahead): asked between the
+// parts of the selection drawn ahead, it looks whether the evaluation has come back, decides the accept
+// test when it has, and says "give up" when the update was accepted.
+struct EvalWatch {
+  Shared& S;
+  const DriverState& D;
+  const FinishPrepared& pre;
+  uint32_t arrivals_due;  // S.eval_arrived once every evaluating wavefront has left its sum
+  bool decided = false, accepted = false;
+  MG_DEV bool operator()() {
+    if (decided) return false;
+    if (__hip_atomic_load(&S.eval_arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != arrivals_due) return false;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    decided = true;
+    accepted = finish_decide(D, pre, tail_waves_sum(S));
+    return accepted;
+  }
+};
+
+// The loop of advance_kernel's SPEC variant (see there).  Two hardware barriers per update: one after
+// the request is posted, one when both the evaluation and the work ahead are over.  The pose table behind
+// an accepted state edge is moved by the other wavefronts alone while the first one already selects the
+// next update (selection and proposal read weights, controls and landmark estimates, never a pose) --
+// unless the driver's next act is growth, which does read poses and waits for them.
+template <bool RB>
+MG_DEV void advance_ahead(DevArgs dp, SharedLds sp, uint32_t c, DriverState& D, WaveRng& rng) {
+  const Dev& d = *(const Dev*)dp;
+  Shared& S = *(Shared*)sp;
+  const bool first_wave = threadIdx.x < 64;
+  const uint32_t tail_waves = (blockDim.x >> 6) - 1u;
+  TailWaves tail(&S.tail_arrivals);
+  uint32_t evals = 0;  // evaluations started so far
+  uint32_t round = 0;  // requests posted so far: they alternate between two slots
+  // the first wavefront's: the update in flight as far as it is prepared and decided
+  FinishPrepared pre{0.0, 0.0, 0.0};
+  bool decided = false, accepted = false, ahead_ok = false;
+  WaveRng::Mark after_test = rng.mark();
+  double r = 0.0;
+#ifdef MG_PHASE_TIMING  // diagnostic build: where the two parties' cycles go, and how the work ahead fares
+  long long dg_serial = 0, dg_ahead = 0, dg_wait0 = 0, dg_eval = 0, dg_wait1 = 0, dg_commit = 0;
+  long long dg_evals = 0, dg_tried = 0, dg_taken = 0, dg_given_up = 0, dg_wasted = 0, dg_ran_out = 0;
+#define MG_AHEAD_CLOCK(v) const long long v = clock64()
+#define MG_AHEAD_ADD(acc, a, b) acc += (b) - (a)
+#define MG_AHEAD_COUNT(acc) ++acc
+#else
+#define MG_AHEAD_CLOCK(v)
+#define MG_AHEAD_ADD(acc, a, b)
+#define MG_AHEAD_COUNT(acc)
+#endif
+  for (;;) {
+    MG_AHEAD_CLOCK(ta0);
+    if (first_wave) {
+      bool commit = false;
+      if (D.awaiting) {  // the end of the update whose evaluation is back: step_with's first half
+        D.awaiting = 0;
+        const uint32_t idx = D.idx;
+        const bool accept = decided ? accepted : finish_decide(D, pre, r);
+        if (accept && ahead_ok) {  // drawn ahead on a false premise
+          rng.restore(after_test);
+          ahead_ok = false;
+          MG_AHEAD_COUNT(dg_wasted);
+        }
+        finish_apply(d, c, D, pre, r, accept);
+        D.accept = accept ? 1 : 0;
+        if (D.pending == PEND_UPDATE) {
+          if (accept) ++D.n_acc;
+        } else if (!accept) {  // rejected re-parenting update: reset the edge weight, :321-322
+          const uint32_t o = D.rp_obs;
+          const size_t fi = size_t(c) * d.Fcap + idx;
+          wt::set(landmark_tree(d, c, D), D.nf, idx,
+                  edge_weight_from_log_pdf(reading_proposal_log_pdf(load_reading(d, o), Vec2{d.fex[fi], d.fey[fi]}), 2.0,
+                                           nullptr));
+          D.w_dirty = 1;
+        }
+        D.pending = PEND_NONE;
+        if (D.op == OP_EVAL_STATE && accept) {
+          D.op = OP_COMMIT;
+          commit = true;
+        }
+      }
+      if (!commit) {
+        D.spec_ready = ahead_ok ? 1 : 0;
+        if (ahead_ok) MG_AHEAD_COUNT(dg_taken);
+        ahead_ok = false;
+        driver_advance(d, c, S, D, rng);
+        if (D.spec_ready) {  // (cannot happen: the driver's next act was checked to be a plain update)
+          D.spec_ready = 0;
+          D.failed = 1;
+        }
+        if (D.op == OP_EVAL_STATE || D.op == OP_EVAL_FEATURE) D.awaiting = 1;
+      }
+      if (threadIdx.x == 0) {  // the request, where the other wavefronts find it
+        Posted& post = S.post[round & 1u];
+        post.op = D.op;
+        post.idx = D.idx;
+        post.q[0] = D.q[0];
+        post.q[1] = D.q[1];
+        post.q[2] = D.q[2];
+        post.Tcur = D.Tcur;
+        post.nf = D.nf;
+        // a commit: does the driver go on to something that reads the pose table?
+        post.join = !(D.stage == ST_STEPS && D.steps_left > 0) && !(D.stage == ST_END_STEPS && D.end_left > 0);
+      }
+    }
+    __syncthreads();
+    MG_AHEAD_CLOCK(ta1);
+    MG_AHEAD_ADD(dg_serial, ta0, ta1);
+    const Posted& post = S.post[round & 1u];
+    ++round;
+    const int op = post.op;
+    if (op == OP_END) break;
+    const uint32_t idx = post.idx;
+    const double qx = post.q[0], qy = post.q[1], qth = post.q[2];
+    const uint32_t Tcur = post.Tcur, nf = post.nf;
+    if (op == OP_COMMIT) {  // the state edge just accepted: the other wavefronts move the pose table
+      const uint32_t join = post.join;
+      if (tail_waves == 0) {
+        WholeBlock everyone;
+        commit_body(dp, c, idx, qx, qy, qth, Tcur, nf, everyone);
+      } else if (!first_wave) {
+        commit_body(dp, c, idx, qx, qy, qth, Tcur, nf, tail);
+      }
+      D.n_moved += Tcur - idx;
+      if (join) __syncthreads();
+      MG_AHEAD_CLOCK(tc1);
+      MG_AHEAD_ADD(dg_commit, ta1, tc1);
+      continue;
+    }
+    ++evals;
+    MG_AHEAD_COUNT(dg_evals);
+    if (first_wave) {
+      pre = finish_prepare(d, c, D, rng);
+      after_test = rng.mark();
+      decided = false;
+      ahead_ok = false;
+      // the driver's next act is another plain update: the one in flight is one, and more are due
+      const bool more = (D.stage == ST_STEPS && D.steps_left > 0) || (D.stage == ST_END_STEPS && D.end_left > 0);
+      if (D.pending == PEND_UPDATE && more && !D.failed) {
+        EvalWatch watch{S, D, pre, evals * tail_waves};
+        rng.ahead = true;
+        rng.ran_out = false;
+        MG_AHEAD_COUNT(dg_tried);
+        const int st = begin_update_core(d, c, S, D, rng, D.spec, watch);
+        ahead_ok = st == BEGIN_OK && !rng.ran_out;
+        if (st == BEGIN_GIVEN_UP) MG_AHEAD_COUNT(dg_given_up);
+        if (rng.ran_out) MG_AHEAD_COUNT(dg_ran_out);
+        rng.ahead = false;
+        rng.ran_out = false;
+        decided = watch.decided;
+        accepted = watch.accepted;
+        if (!ahead_ok) rng.restore(after_test);
+      }
+      MG_AHEAD_CLOCK(tb1);
+      MG_AHEAD_ADD(dg_ahead, ta1, tb1);
+    } else {
+      unsigned long long units;
+      inline_eval<RB>(dp, sp, c, op, idx, qx, qy, qth, nf, units, tail);  // leaves the sums in S.red
+      if (tail.tid() == 0) S.eval_units = units;
+      MG_AHEAD_CLOCK(tb1);
+      MG_AHEAD_ADD(dg_eval, ta1, tb1);
+    }
+    MG_AHEAD_CLOCK(tw0);
+    __syncthreads();
+    MG_AHEAD_CLOCK(tw1);
+    if (first_wave)
+      MG_AHEAD_ADD(dg_wait0, tw0, tw1);
+    else
+      MG_AHEAD_ADD(dg_wait1, tw0, tw1);
+    r = tail_waves_sum(S);
+    D.n_units += S.eval_units;
+    if (op == OP_EVAL_STATE) ++D.n_state;
+  }
+#ifdef MG_PHASE_TIMING
+  // slots of this variant: 0 serial step, 1 work ahead, 2 first wavefront waiting for the evaluation,
+  // 3 evaluation, 4 the others waiting for the first, 5 commit; 8.. counts: evaluations, selections
+  // tried ahead, taken, given up early, completed but dropped, out of generator words
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    S.phase[0] = dg_serial, S.phase[1] = dg_ahead, S.phase[2] = dg_wait0, S.phase[5] = dg_commit;
+    S.phase[8] = dg_evals, S.phase[9] = dg_tried, S.phase[10] = dg_taken, S.phase[11] = dg_given_up;
+    S.phase[12] = dg_wasted, S.phase[13] = dg_ran_out, S.phase[14] = 0, S.phase[15] = 0, S.phase[7] = 0;
+  }
+  if (threadIdx.x == 64) S.phase[3] = dg_eval, S.phase[4] = dg_wait1;
+  __syncthreads();
+#endif
+}
+#endif
 
 // grid = chains, block = threads_per_chain.  first_tn = the next timestep the
 // chains have not processed yet; Tcur0 = state edges grown so far.  `d` must
@@ -1668,9 +2098,20 @@ struct TreeTops {
 // SOLO: the serial program compiled into the kernel as well, for launches of so few chains that a chain
 // has its CU to itself and the serial program IS the launch's critical path (one mcmc_slam instance on
 // a Plaza-sized log): no call, no registers saved and reloaded around it.
-template <bool RB, bool SOLO = false>
+//
+// SPEC (with SOLO, workgroups of at least two wavefronts): while the wavefronts after the first evaluate
+// update k, the first one runs ahead -- it draws the uniform of k's accept test (nothing else draws
+// between a proposal and that uniform, mcmc_slam.hpp:375-408), prepares the parts of the test that do not
+// need the evaluation, and then selects and proposes update k + 1 as it will be IF k is rejected (a
+// rejected update changes nothing but the generator).  It looks now and then whether k's evaluation has
+// come back; if k turns out accepted it drops what it has drawn ahead, puts the generator back to just
+// after the accept test's uniform and selects afresh once k is applied.  Every draw, weight and sum is the
+// one the sequential order produces; only the time at which it is computed differs.  For data on which
+// an update's serial part outlasts its evaluation (a Plaza-sized log: 650 readings per update).
+template <bool RB, bool SOLO = false, bool SPEC = false>
 __global__ void __launch_bounds__(SOLO ? 256 : 1024) advance_kernel(Dev d, uint32_t first_tn, uint32_t Tcur0, uint32_t upto, uint32_t steps_per_ts,
                                uint32_t end_steps, uint32_t grow, TreeTops tops) {
+  static_assert(SOLO || !SPEC, "running ahead needs the serial program compiled in");
   __shared__ Shared S;
   extern __shared__ double tree_tops[];
   const DevArgs dp = (DevArgs)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1711,11 +2152,18 @@ __global__ void __launch_bounds__(SOLO ? 256 : 1024) advance_kernel(Dev d, uint3
     D.Ws = D.Wf = 0.0;
     D.arr = D.arr_end = D.steps_left = 0;
   }
+  if (threadIdx.x == 0) {
+    S.tail_arrivals = 0;
+    S.eval_arrived = 0;
+  }
   __syncthreads();
   MG_STAMP(tk0);
   double r = 0.0;
 #if defined(__HIP_DEVICE_COMPILE__)
   WaveRng wave_rng(S.rng);  // used by the first wavefront of the SOLO variant only
+  if (SPEC) {
+    advance_ahead<RB>(dp, sp, c, D, wave_rng);
+  } else
 #endif
   for (;;) {
     MG_STAMP(td0);
@@ -1746,9 +2194,10 @@ __global__ void __launch_bounds__(SOLO ? 256 : 1024) advance_kernel(Dev d, uint3
     const double qx = S.drv.q[0], qy = S.drv.q[1], qth = S.drv.q[2];
     const uint32_t Tcur = S.drv.Tcur, nf = S.drv.nf;
     if (op == OP_COMMIT) {  // the state edge just accepted: all lanes move the pose table, then lane 0 goes on
-      if (SOLO)
-        commit_body(dp, c, idx, qx, qy, qth, Tcur, nf);
-      else
+      if (SOLO) {
+        WholeBlock everyone;
+        commit_body(dp, c, idx, qx, qy, qth, Tcur, nf, everyone);
+      } else
         piece_commit(dp, c, idx, qx, qy, qth, Tcur, nf);
       if (SOLO || threadIdx.x == 0) D.n_moved += Tcur - idx;  // poses idx+1 .. Tcur rewritten
       __syncthreads();
@@ -1757,7 +2206,8 @@ __global__ void __launch_bounds__(SOLO ? 256 : 1024) advance_kernel(Dev d, uint3
       continue;
     }
     unsigned long long units;
-    r = inline_eval<RB>(dp, sp, c, op, idx, qx, qy, qth, nf, units);
+    WholeBlock everyone;
+    r = inline_eval<RB>(dp, sp, c, op, idx, qx, qy, qth, nf, units, everyone);
     if (SOLO || threadIdx.x == 0) {
       D.n_units += units;
       if (op == OP_EVAL_STATE) ++D.n_state;

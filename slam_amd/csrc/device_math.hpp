@@ -488,6 +488,26 @@ struct WaveRng {
   int base, n = 0, pos = 0;  // the window starts at word `base`, holds n outputs, `pos` of them are used
   int has_saved;
   double saved;
+  // Drawing ahead on a premise that may turn out false: mark() notes where the stream stands, restore()
+  // goes back there.  Everything a draw changes is in this object except the generator's 624 words,
+  // which the twist at the end of a block rewrites in place -- so while `ahead` is set the twist is not
+  // done: the stream reports `ran_out` instead and hands out meaningless (but finite) numbers until the
+  // caller, who must check the flag, restores the mark.
+  bool ahead = false, ran_out = false;
+  struct Mark {
+    uint32_t win;
+    int base, n, pos, has_saved;
+    double saved;
+  };
+  MG_DEV Mark mark() const { return Mark{win, base, n, pos, has_saved, saved}; }
+  MG_DEV void restore(const Mark& m) {
+    win = m.win;
+    base = m.base;
+    n = m.n;
+    pos = m.pos;
+    has_saved = m.has_saved;
+    saved = m.saved;
+  }
   MG_DEV explicit WaveRng(RngState& s) : st(s), base(s.idx), has_saved(s.has_saved), saved(s.saved) {}
   MG_DEV void flush() {
     st.idx = base + pos;
@@ -497,6 +517,11 @@ struct WaveRng {
   MG_DEV void load_window() {
     int idx = base + pos;
     if (idx >= 624) {
+      if (ahead) {  // the block's end: see `ahead`
+        ran_out = true;
+        pos = 0;
+        return;
+      }
       rng_refill_wave(st);
       idx = 0;
     }
@@ -535,6 +560,7 @@ struct WaveRng {
     // (a trial fails with probability 1 - pi/4; the bound only keeps corrupted state from spinning)
     for (int guard = 0; guard < 4096; ++guard) {
       if (pos >= n) load_window();
+      if (ran_out) return 0.0;
       int trials = (n - pos) >> 2;  // whole trials (four outputs each) left in the window
       if (trials == 0) {  // the next trial straddles the window's end: drawn the serial way
         const double x = 2.0 * uniform() - 1.0;

@@ -352,6 +352,8 @@ constexpr uint32_t kSoloMaxChains = 256;  // chains (= CUs) up to which a handle
 // by launches of at most this many wavefronts, i.e. when every wavefront has a SIMD to itself anyway and the
 // serial program is the launch's critical path: 256 chains of 256 lanes, 1024 chains of 64
 constexpr uint32_t kSoloMaxWaves = 1024;
+// ... and its run-ahead form (SPEC) by those whose data holds at most this many readings
+constexpr uint32_t kAheadMaxReadings = 32768;
 std::mutex g_static_scratch_mutex;
 void* g_static_scratch[kMaxDevices] = {};
 
@@ -548,7 +550,7 @@ int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out) {
                             : (cfg->max_observations <= 32768 && cfg->max_chains > kSoloMaxChains ? 64 : 256);
   if (nthr < 64 || nthr > 1024 || !is_pow2(nthr))
     return fail(nullptr, MCMCGPU_ERR_ARGUMENT, "threads_per_chain must be a power of two in [64, 1024]");
-  if (cfg->serial_program > 2) return fail(nullptr, MCMCGPU_ERR_ARGUMENT, "serial_program must be 0, 1 or 2");
+  if (cfg->serial_program > 3) return fail(nullptr, MCMCGPU_ERR_ARGUMENT, "serial_program must be 0, 1, 2 or 3");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(nullptr, MCMCGPU_ERR_HIP, "no HIP device available (this library has no CPU path)");
@@ -1032,10 +1034,16 @@ int mcmcgpu_advance(mcmcgpu_handle h, uint32_t upto, uint32_t steps_per_timestep
   const size_t dyn_lds = (size_t(tops.sw_n) + tops.fw_n) * sizeof(double);
   // one kernel per observation model; few chains take the variant with the serial program compiled in
   const bool solo = h->nthreads <= 256 &&  // that variant is built for at most 256 lanes
-                    (h->cfg.serial_program == 2 ||
+                    (h->cfg.serial_program >= 2 ||
                      (h->cfg.serial_program == 0 && uint64_t(h->chains) * (h->nthreads / 64) <= kSoloMaxWaves));
-  auto* const kernel = h->cfg.range_bearing ? (solo ? advance_kernel<true, true> : advance_kernel<true, false>)
-                                            : (solo ? advance_kernel<false, true> : advance_kernel<false, false>);
+  // ... and of those, launches on sparse data (an update's serial part outlasts its evaluation) let the first
+  // wavefront run ahead with the next update's selection while the others evaluate
+  const bool ahead = solo && h->nthreads >= 128 &&
+                     (h->cfg.serial_program == 3 || (h->cfg.serial_program == 0 && h->d.N <= kAheadMaxReadings));
+  auto* const kernel =
+      h->cfg.range_bearing
+          ? (ahead ? advance_kernel<true, true, true> : solo ? advance_kernel<true, true, false> : advance_kernel<true, false, false>)
+          : (ahead ? advance_kernel<false, true, true> : solo ? advance_kernel<false, true, false> : advance_kernel<false, false, false>);
   if (dyn_lds > 48 * 1024 && h->advance_lds_raised.insert(reinterpret_cast<const void*>(kernel)).second)
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    int(kLdsPerCu - kAdvanceStaticLds)));

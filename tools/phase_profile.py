@@ -61,7 +61,7 @@ def plaza(a):
     ctrl_mean, ctrl_std = synthetic.control_models(data["controls"], data["dt"])
     obs_f, order = dataset_cache.dense_landmarks(data["obs_id"])
     seeds = capi.seed_sequence(42, 6)
-    g = capi.McmcGpu(1, T, len(order), N, threads_per_chain=a.threads_per_chain)
+    g = capi.McmcGpu(1, T, len(order), N, threads_per_chain=a.threads_per_chain, serial_program=a.serial_program)
     g.upload_problem(ctrl_mean, ctrl_std, data["obs_t"], obs_f, data["obs_range"], np.full(N, 1.0), len(order))
     g.init_chains(np.array([seeds[2]], dtype=np.uint32), capi.uniform_sequence(int(seeds[1]), len(order)))
     g.debug_phase_cycles(reset=True)
@@ -77,6 +77,17 @@ def plaza(a):
     print(f"{a.plaza}: {T} timesteps, {N} readings, wall {wall:.3f} s, {nprop} updates ({int(s[0][0])} state edges), "
           f"{nacc} accepted, {units / max(nprop, 1):.0f} units per update, {int(s[1][0]) / max(nacc, 1):.0f} poses moved per accept")
     print(f"whole kernel {whole / 1e6:.1f} Mcycles = {whole / max(nprop, 1):.0f} cycles per update")
+    if a.serial_program in (0, 3) and (a.threads_per_chain == 0 or a.threads_per_chain >= 128):
+        # the run-ahead variant books its cycles differently (advance_ahead in chain_kernels.hpp)
+        ev = max(int(cyc[8]), 1)
+        for slot, name in [(0, "first wavefront: serial step"), (1, "first wavefront: work ahead"),
+                           (2, "first wavefront: waiting for the evaluation"), (3, "others: evaluation"),
+                           (4, "others: waiting for the first wavefront"), (5, "commit")]:
+            print(f"  {name:44s} {100.0 * cyc[slot] / whole:6.2f} % of kernel   {cyc[slot] / max(nprop, 1):10.0f} cycles per update")
+        print(f"  evaluations {int(cyc[8])}: next update selected ahead {int(cyc[9])} ({100.0 * cyc[9] / ev:.1f} %), taken {int(cyc[10])} "
+              f"({100.0 * cyc[10] / ev:.1f} %), given up early {int(cyc[11])}, finished but dropped {int(cyc[12])}, "
+              f"out of generator words {int(cyc[13])}")
+        return
     for i in range(6):
         print(f"  {NAMES[i]:28s} {100.0 * cyc[i] / whole:6.2f} % of kernel   {cyc[i] / max(nprop, 1):10.0f} cycles per update")
     rest = whole - float(cyc[:6].sum())
@@ -91,6 +102,7 @@ def main():
     ap.add_argument("--timesteps", type=int, default=100_000)
     ap.add_argument("--landmarks", type=int, default=1000)
     ap.add_argument("--threads-per-chain", type=int, default=0)
+    ap.add_argument("--serial-program", type=int, default=0, help="mcmcgpu_config.serial_program")
     ap.add_argument("--plaza", default="", help="Plaza1 or Plaza2: the online replay of bench.py's plaza line instead")
     a = ap.parse_args()
     if a.plaza:
