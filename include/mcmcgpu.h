@@ -457,7 +457,8 @@ int mcmcgpu_selftest_range(int32_t device, uint32_t n, const double* dx, const d
 
 /* Self-test of the serial part's wavefront forms (used when it is compiled into the kernel,
  * mcmcgpu_config.serial_program): n draws of the chain generator seeded with `seed`, kinds[i] = 0 a
- * uniform (random_source::uniform, src/utility/random.hpp:25-31) or 1 a normal (:33-39), once by the
+ * uniform (random_source::uniform, src/utility/random.hpp:25-31), 1 a normal (:33-39), 2 / 3 three / two
+ * normals drawn as one batch (output: first + 2 second + 4 third), once by the
  * one-lane code and once by the 64-lane code; and for each of n_search numbers u in [0, 1] the index
  * bitree<double>::binary_search(total * u) (src/utility/bitree.hpp:302-321) finds in a tree of
  * tree_n weights, by both forms.  The two outputs of each pair must be identical. */

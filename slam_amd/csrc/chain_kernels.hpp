@@ -1279,10 +1279,9 @@ MG_DEV void write_trace(const Dev& d, uint32_t c, const DriverState& D, int kind
 template <class R>
 MG_DEV Vec2 propose_landmark(const Dev& d, R& rng, const Reading& m) {
   if (m.bearing) {
-    double v0 = rng.normal(), v1 = rng.normal();
-    v0 = v0 * m.sd + m.mu;
-    v1 = v1 * m.bsd + m.bmu;
-    return polar(v0, v1);
+    double v[2];
+    rng.normals(v, 2);
+    return polar(v[0] * m.sd + m.mu, v[1] * m.bsd + m.bmu);
   }
   double r, u;
   if (d.uniform_first) {
@@ -1372,7 +1371,7 @@ MG_DEV int begin_update_core(const Dev& d, uint32_t c, Shared& S, DriverState& D
     load_control(d, t, mu, sd, ld);
     // the current relative pose's log density is kept from when that pose was set
     const double old_pll = d.clp[size_t(c) * d.Tcap + t];
-    for (int i = 0; i < 3; ++i) v[i] = rng.normal();
+    rng.normals(v, 3);
     for (int i = 0; i < 3; ++i) v[i] = v[i] * sd[i] + mu[i];
     MG_MARK(S, 11);
     if (watch()) return BEGIN_GIVEN_UP;
@@ -3168,17 +3167,26 @@ __global__ void __launch_bounds__(kScanLanes) scan_affine_kernel(uint32_t n, int
 }
 
 // Self-tests of the wavefront forms of the generator and of the weight-tree descent against the serial
-// ones they must equal bit for bit.  One workgroup of 64 lanes each.  kinds[i]: 0 = uniform, 1 = normal.
+// ones they must equal bit for bit.  One workgroup of 64 lanes each.  kinds[i]: 0 = uniform, 1 = normal,
+// 2 / 3 = three / two normals drawn as a batch (their weighted sum is the output).
 struct SelftestLds {
   double pad[16];  // the generator's state sits where a chain's does: not at the start of the workgroup's LDS
   RngState rng;
 };
+template <class R>
+MG_DEV double selftest_draw(R& r, uint8_t kind) {
+  if (kind == 0) return r.uniform();
+  if (kind == 1) return r.normal();
+  double v[3] = {0.0, 0.0, 0.0};
+  r.normals(v, kind == 2 ? 3 : 2);
+  return v[0] + 2.0 * v[1] + 4.0 * v[2];
+}
 __global__ void __launch_bounds__(64) serial_draws_selftest_kernel(uint32_t seed, uint32_t n, const uint8_t* kinds, double* out) {
   __shared__ SelftestLds L;
   if (threadIdx.x == 0) {
     rng_seed(L.rng, seed);
     SerialRng r{L.rng};
-    for (uint32_t i = 0; i < n; ++i) out[i] = kinds[i] ? r.normal() : r.uniform();
+    for (uint32_t i = 0; i < n; ++i) out[i] = selftest_draw(r, kinds[i]);
   }
 }
 __global__ void __launch_bounds__(64) wave_draws_selftest_kernel(uint32_t seed, uint32_t n, const uint8_t* kinds, double* out) {
@@ -3189,7 +3197,7 @@ __global__ void __launch_bounds__(64) wave_draws_selftest_kernel(uint32_t seed, 
   for (uint32_t i0 = 0; i0 < n; i0 += 7) {  // a fresh window object every few draws, as one per update
     WaveRng r(L.rng);
     for (uint32_t i = i0; i < n && i < i0 + 7; ++i) {
-      const double v = kinds[i] ? r.normal() : r.uniform();
+      const double v = selftest_draw(r, kinds[i]);
       if (threadIdx.x == 0) out[i] = v;
     }
     r.flush();

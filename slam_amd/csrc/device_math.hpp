@@ -115,7 +115,11 @@ MG_DEV void control_observe(const Pose& dp, double out[3]) {
 
 MG_DEV Pose control_inv_observe(const double v[3]) {
   const double s = v[0], alpha = v[1], beta = v[2], r = s / alpha;
-  if (isfinite(r)) return Pose{r * sin(alpha), r - r * cos(alpha), alpha + beta};
+  if (isfinite(r)) {
+    double sn, cs;
+    sincos(alpha, &sn, &cs);  // one argument reduction for the pair
+    return Pose{r * sn, r - r * cs, alpha + beta};
+  }
   return Pose{s, 0.0, beta};
 }
 
@@ -152,7 +156,11 @@ MG_DEV double range_proposal_log_pdf(double mu, double sd, const Vec2& p) {
   return range_log_pdf(mu, sd, vec_norm(p)) - log(2 * kPi);
 }
 
-MG_DEV Vec2 polar(double dist, double dir) { return Vec2{dist * cos(dir), dist * sin(dir)}; }
+MG_DEV Vec2 polar(double dist, double dir) {
+  double sn, cs;
+  sincos(dir, &sn, &cs);
+  return Vec2{dist * cs, dist * sn};
+}
 
 // ---- one landmark reading as a distribution ----------------------------------
 // Both observation models of src/planar_robot/range_bearing_model.hpp behind a
@@ -189,6 +197,18 @@ MG_DEV double edge_weight_from_log_pdf(double log_pdf, double dim, double* log_w
 // node[i] holds the sum of the values (parent(i), i], parent(i) = i & (i-1).
 // Only additions and negations are used, in the reference's exact order, so
 // totals and searched indices are identical to the CPU for identical weights.
+// The serial part runs in one lane, or in all lanes of a wavefront on the same data.  Either way its
+// control flow is the same in every active lane, which the compiler cannot see once a value has come
+// out of memory: it then guards every branch with a lane mask and keeps indices in vector registers.
+// A ballot / first-lane read says it outright, and loop counters, indices and branches become scalar.
+#if defined(__HIP_DEVICE_COMPILE__)
+MG_DEV bool uniformly(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
+MG_DEV uint32_t uniform_u32(uint32_t v) { return uint32_t(__builtin_amdgcn_readfirstlane(int(v))); }
+#else
+MG_DEV bool uniformly(bool p) { return p; }
+MG_DEV uint32_t uniform_u32(uint32_t v) { return v; }
+#endif
+
 namespace wt {
 MG_DEV uint32_t parent(uint32_t i) { return i & (i - 1); }
 MG_DEV uint32_t next_sibling(uint32_t i) { return i + (i & (0u - i)); }
@@ -244,21 +264,48 @@ struct Cached {
   }
 };
 
+// node(i) + (node(parent(i)) + ( ... )) up to, not including, `ancestor`.  Any lane for itself.
 template <class N>
 MG_DEV double sum_to_ancestor(const N& node, uint32_t i, uint32_t ancestor) {
   double result = 0.0;
   for (; i != ancestor; i = parent(i)) result = node.ld(i) + result;
   return result;
 }
+// The same for the serial program (every active lane on the same arguments): added in the same order,
+// but asked for four at a time (which nodes they are is bit arithmetic on i alone), scalar indices.
+template <class N>
+MG_DEV double sum_to_ancestor_serial(const N& node, uint32_t i_in, uint32_t ancestor_in) {
+  uint32_t i = uniform_u32(i_in);
+  const uint32_t ancestor = uniform_u32(ancestor_in);
+  double result = 0.0;
+  while (i != ancestor) {
+    const uint32_t j1 = parent(i);
+    const bool v1 = j1 != ancestor;
+    const uint32_t j2 = v1 ? parent(j1) : ancestor;
+    const bool v2 = j2 != ancestor;
+    const uint32_t j3 = v2 ? parent(j2) : ancestor;
+    const bool v3 = j3 != ancestor;
+    const double a0 = node.ld(i);
+    const double a1 = v1 ? node.ld(j1) : 0.0;
+    const double a2 = v2 ? node.ld(j2) : 0.0;
+    const double a3 = v3 ? node.ld(j3) : 0.0;
+    result = a0 + result;
+    if (v1) result = a1 + result;
+    if (v2) result = a2 + result;
+    if (v3) result = a3 + result;
+    i = v3 ? parent(j3) : ancestor;
+  }
+  return result;
+}
 template <class N>
 MG_DEV double total(const N& node, uint32_t n) {
   if (n == 0) return 0.0;
-  return node.ld(0) + sum_to_ancestor(node, n - 1, 0);
+  return node.ld(0) + sum_to_ancestor_serial(node, n - 1, 0);
 }
 template <class N>
 MG_DEV double node_value_for(const N& node, uint32_t i, double v) {
   if (i == 0) return v;
-  return sum_to_ancestor(node, i - 1, parent(i)) + v;
+  return sum_to_ancestor_serial(node, i - 1, parent(i)) + v;
 }
 template <class N>
 MG_DEV double get(const N& node, uint32_t i) {
@@ -286,25 +333,69 @@ MG_DEV void set(const N& node, uint32_t n, uint32_t i, double v) {
     }
   node.st(i, new_value);
 }
-// index k with prefix(k) <= value < prefix(k+1); may return n when value >= total
-template <class N>
-MG_DEV uint32_t search(const N& node, uint32_t n, double value) {
-  if (n == 0 || value < node.ld(0)) return 0;
+// index k with prefix(k) <= value < prefix(k+1); may return n when value >= total.
+// The reference's descent (bitree.hpp:302-321), comparison for comparison and addition for addition, two
+// levels per round: the node the next comparison asks for and the two that the one after it can ask for
+// are requested together, so a round waits for memory once; indices and branches are scalar.
+template <class Load, class Warm>
+MG_DEV uint32_t search_by(Load ld, Warm warm, uint32_t n_in, double value) {
+  const uint32_t n = uniform_u32(n_in);
+  if (n == 0) return 0;
+  double origin = ld(0u);
+  if (uniformly(value < origin)) return 0;
   uint32_t lo = 0, hi = n;
-  double origin = node.ld(0);
   while (lo + 1 < hi) {
     const uint32_t mid = child_containing(lo, hi - 1);
-    node.warm(lo, n, mid);
-    const double at_mid = node.ld(mid);
-    if (value < origin + at_mid)
+    const bool open_l = lo + 1 < mid, open_r = mid + 1 < hi;
+    const uint32_t mid_l = open_l ? child_containing(lo, mid - 1) : mid;
+    const uint32_t mid_r = open_r ? child_containing(mid, hi - 1) : mid;
+    warm(lo, n, mid);
+    const double at_mid = ld(mid), at_l = ld(mid_l), at_r = ld(mid_r);
+    const double s = origin + at_mid;
+    if (uniformly(value < s)) {
       hi = mid;
-    else {
+      if (open_l) {
+        const double sl = origin + at_l;
+        if (uniformly(value < sl)) {
+          hi = mid_l;
+        } else {
+          lo = mid_l;
+          origin = sl;
+        }
+      }
+    } else {
       lo = mid;
-      origin += at_mid;
+      origin = s;
+      if (open_r) {
+        const double sr = s + at_r;
+        if (uniformly(value < sr)) {
+          hi = mid_r;
+        } else {
+          lo = mid_r;
+          origin = sr;
+        }
+      }
     }
   }
   return hi;
 }
+template <class N>
+MG_DEV uint32_t search(const N& node, uint32_t n, double value) {
+  return search_by([&](uint32_t i) { return node.ld(i); }, [&](uint32_t lo, uint32_t nn, uint32_t mid) { node.warm(lo, nn, mid); },
+                   n, value);
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// a tree whose every node is in LDS (copy at stride 1): no choice to make per node
+MG_DEV uint32_t search(const Cached& node, uint32_t n, double value) {
+  if (uniformly(node.top != 0 && node.shift == 0)) {
+    const LdsDoubles all = node.lds();
+    return search_by([&](uint32_t i) { return all[i]; }, [](uint32_t, uint32_t, uint32_t) {}, n, value);
+  }
+  return search_by([&](uint32_t i) { return node.ld(i); }, [&](uint32_t lo, uint32_t nn, uint32_t mid) { node.warm(lo, nn, mid); },
+                   n, value);
+}
+#endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
 MG_DEV double readlane_f64(double v, int lane) {
@@ -444,6 +535,9 @@ struct SerialRng {
   RngState& st;
   MG_DEV double uniform() { return rng_uniform(st); }
   MG_DEV double normal() { return rng_normal(st); }
+  MG_DEV void normals(double* out, int count) {
+    for (int i = 0; i < count; ++i) out[i] = rng_normal(st);
+  }
   MG_DEV void flush() {}
 };
 
@@ -593,6 +687,60 @@ struct WaveRng {
       return wt::readlane_f64(y * mult, first);
     }
     return __builtin_nan("");
+  }
+  // `count` (at most 4) normals in a row, the same numbers as `count` calls of normal().  The trials that
+  // one call evaluates side by side are the trials the next call would evaluate: the second accepted
+  // trial of the same window serves the call after the next, and so on, so that one evaluation (one
+  // logarithm, root and division, in every lane for its own trial) usually serves them all.
+  MG_DEV void normals(double* out, int count) {
+    int got = 0;
+    const int lane = threadIdx.x & 63;
+    for (int guard = 0; guard < 4096 && got < count; ++guard) {
+      if (has_saved) {  // the second number of the last accepted trial comes first
+        has_saved = 0;
+        out[got++] = saved;
+        continue;
+      }
+      if (pos >= n) load_window();
+      if (ran_out) break;
+      int trials = (n - pos) >> 2;
+      if (trials == 0) {  // the next trial straddles the window's end: one call the usual way
+        out[got++] = normal();
+        continue;
+      }
+      if (trials > 16) trials = 16;
+      const int at = (pos + 4 * lane) & 63;
+      const uint32_t a0 = uint32_t(__shfl(int(win), at)), a1 = uint32_t(__shfl(int(win), (at + 1) & 63));
+      const uint32_t b0 = uint32_t(__shfl(int(win), (at + 2) & 63)), b1 = uint32_t(__shfl(int(win), (at + 3) & 63));
+      const double x = 2.0 * canonical(a0, a1) - 1.0;
+      const double y = 2.0 * canonical(b0, b1) - 1.0;
+      const double r2 = x * x + y * y;
+      const bool ok = lane < trials && !(r2 > 1.0 || r2 == 0.0);
+      unsigned long long mask = __ballot(ok);
+      if (mask == 0) {
+        pos += 4 * trials;
+        continue;
+      }
+      const double mult = sqrt(-2 * log(r2) / r2);
+      const double from_y = y * mult, from_x = x * mult;
+      int used = 0;  // last trial whose numbers were taken
+      while (mask != 0 && got < count) {  // accepted trials in their order, as long as numbers are wanted
+        used = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        out[got++] = wt::readlane_f64(from_y, used);
+        const double second = wt::readlane_f64(from_x, used);
+        if (got < count) {
+          out[got++] = second;
+        } else {
+          saved = second;
+          has_saved = 1;
+        }
+      }
+      // enough numbers: the stream stands behind the last trial used; numbers still wanted: the window's
+      // accepted trials ran out, and the rejected ones behind the last of them are used up as well
+      pos += (got >= count) ? 4 * (used + 1) : 4 * trials;
+    }
+    for (; got < count; ++got) out[got] = 0.0;  // only after ran_out
   }
 };
 #endif

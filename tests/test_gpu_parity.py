@@ -1015,6 +1015,8 @@ def test_wavefront_forms_of_generator_and_descent_equal_the_serial_ones(seed):
     some twenty times; the trees range from one node to Plaza1's size and include zero weights."""
     rng = np.random.default_rng(seed)
     kinds = (rng.random(4000) < 0.45).astype(np.uint8)
+    kinds[rng.random(4000) < 0.2] = 2  # three normals as one batch (a state-edge proposal)
+    kinds[rng.random(4000) < 0.05] = 3  # two (a range-and-bearing landmark proposal)
     for tree_n in (1, 2, 3, 5, 64, 65, 1000, 9657):
         weights = rng.exponential(1.0, tree_n) * (rng.random(tree_n) > 0.1)
         weights[0] = max(weights[0], 1e-3)
