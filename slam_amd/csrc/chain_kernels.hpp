@@ -393,14 +393,39 @@ struct TailWaves {
   }
 };
 
+// Inclusive prefix sums over a wavefront (lane 63 ends up with the wavefront's sum) by data-parallel
+// primitives: lanes shifted inside their row of 16 by 1, 2, 4, 8, then lane 15 of a row added to the
+// row after it, then lane 31 to the upper half.  Six register-to-register steps; the shuffle
+// instructions these replace go through the LDS crossbar and cost a lone wavefront an LDS latency each.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int CTRL, int ROWS>
+MG_DEV uint32_t dpp_take(uint32_t v) {  // the value of the lane that CTRL names, 0 where there is none
+  return uint32_t(__builtin_amdgcn_update_dpp(0, int(v), CTRL, ROWS, 0xF, false));
+}
+template <int CTRL, int ROWS>
+MG_DEV double dpp_take(double v) {
+  return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWS, 0xF, false),
+                          __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWS, 0xF, false));
+}
+template <class T>
+MG_DEV T wave_prefix_sums(T v) {
+  v += dpp_take<0x111, 0xF>(v);  // row_shr:1
+  v += dpp_take<0x112, 0xF>(v);  // row_shr:2
+  v += dpp_take<0x114, 0xF>(v);  // row_shr:4
+  v += dpp_take<0x118, 0xF>(v);  // row_shr:8
+  v += dpp_take<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+  v += dpp_take<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+#else
+template <class T>
+MG_DEV T wave_prefix_sums(T v) { return v; }
+#endif
+
 template <class Team>
 MG_DEV uint32_t block_scan_u32(uint32_t v, Shared& S, uint32_t& total, Team& tm) {
   const int lane = tm.tid() & 63, wave = tm.tid() >> 6, nwaves = tm.size() >> 6;
-#pragma unroll
-  for (int dd = 1; dd < 64; dd <<= 1) {
-    const uint32_t o = __shfl_up(v, dd);
-    if (lane >= dd) v += o;
-  }
+  v = wave_prefix_sums(v);
   if (lane == 63) S.wcount[wave] = v;
   tm.sync();
   uint32_t before = 0, all = 0;
@@ -421,9 +446,8 @@ MG_DEV uint32_t block_scan_u32(uint32_t v, Shared& S, uint32_t& total) {
 template <class Team>
 MG_DEV double block_sum(double v, Shared& S, Team& tm) {
   const int lane = tm.tid() & 63, wave = tm.tid() >> 6, nwaves = tm.size() >> 6;
-#pragma unroll
-  for (int dd = 32; dd > 0; dd >>= 1) v += __shfl_down(v, dd);
-  if (lane == 0) S.red[wave] = v;
+  v = wave_prefix_sums(v);
+  if (lane == 63) S.red[wave] = v;
   tm.sync();
   double r = 0.0;
   if (tm.tid() == 0)
@@ -438,9 +462,8 @@ MG_DEV double block_sum(double v, Shared& S) {
 MG_DEV double WholeBlock::sum(double v, Shared& S) { return block_sum(v, S, *this); }
 MG_DEV double TailWaves::sum(double v, Shared& S) {
 #if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-  for (int dd = 32; dd > 0; dd >>= 1) v += __shfl_down(v, dd);
-  if ((threadIdx.x & 63u) == 0) {
+  v = wave_prefix_sums(v);
+  if ((threadIdx.x & 63u) == 63u) {
     S.red[tid() >> 6] = v;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __hip_atomic_fetch_add(&S.eval_arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -918,11 +941,16 @@ MG_DEV double eval_feature_edge(const Dev& d, uint32_t c, Shared& S, uint32_t f,
 // for timesteps the table does not cover yet (data appended since the last layout), the timestep of
 // every 32nd reading, which narrows the range to at most 32 readings, so the search touches a few
 // cache lines instead of log2(hi - lo) scattered ones.
-MG_DEV uint32_t split_readings(const Dev& d, uint32_t f, uint32_t lo, uint32_t hi, uint32_t t) {
+// The table entry that split_readings consults for landmark f and timestep t (any entry when there is no table).
+MG_DEV TimeBlock time_block_of(const Dev& d, uint32_t f, uint32_t t) {
+  if (!d.tblk_n) return TimeBlock{0, 0, kNoRun, 0};
+  const uint32_t q = t >> d.tblk_shift;
+  return d.tblk[size_t(q < d.tblk_n ? q : d.tblk_n) * d.Fcap + f];
+}
+MG_DEV uint32_t split_readings(const Dev& d, uint32_t f, uint32_t lo, uint32_t hi, uint32_t t, const TimeBlock& tb) {
   uint32_t a = lo, b = hi;
   if (d.tblk_n) {
     const uint32_t q = t >> d.tblk_shift;
-    const TimeBlock tb = d.tblk[size_t(q < d.tblk_n ? q : d.tblk_n) * d.Fcap + f];
     const uint32_t ra = lo + tb.before;
     if (q < d.tblk_n) {
       if (tb.run_from != kNoRun) {  // readings ra, ra + 1, ... were taken at run_from, run_from + 1, ...
@@ -967,6 +995,10 @@ MG_DEV uint32_t split_readings(const Dev& d, uint32_t f, uint32_t lo, uint32_t h
   return a;
 }
 
+MG_DEV uint32_t split_readings(const Dev& d, uint32_t f, uint32_t lo, uint32_t hi, uint32_t t) {
+  return split_readings(d, f, lo, hi, t, time_block_of(d, f, t));
+}
+
 // The four rigid motions of a state-edge proposal, each with the cosine and sine of its angle: poses
 // t and t + 1, the proposed relative pose and its inverse.  The four sincos evaluations are
 // independent, so lanes 4k .. 4k+3 of every wavefront take one each and exchange the results.
@@ -999,8 +1031,67 @@ MG_DEV double eval_state_edge(const Dev& d, uint32_t c, Shared& S, uint32_t t, c
                               unsigned long long& units, Team& tm) {
   const uint32_t tid = tm.tid(), nthr = tm.size();
   const uint32_t segcap = nthr < uint32_t(kMaxSeg) ? nthr : uint32_t(kMaxSeg);
-  const ProposalFrames fr = proposal_frames(world_pose(d, c, t), world_pose(d, c, t + 1), q);
   const size_t fbase = size_t(c) * d.Fcap;
+  if (nf <= 64) {
+    // A wavefront's worth of landmarks: the team's first wavefront prepares them all, every landmark a
+    // segment (those without affected readings an empty one), with the prefix sums taken inside the
+    // wavefront -- one barrier instead of three.  Everything the set-up reads -- poses t and t + 1, the
+    // lane's landmark, its time-block entry -- is asked for before anything is computed: one wait for
+    // memory instead of three in a row (a lone wavefront has nothing else to do meanwhile).
+    MG_STAMP(ts0);
+    if (tid < 64) {
+      const Pose Pt = world_pose(d, c, t), Pt1 = world_pose(d, c, t + 1);
+      const uint32_t f = tid < nf ? tid : 0;
+      const uint32_t lo = d.foff[f], cnt = d.fcnt[fbase + f], pt = d.fpt[fbase + f];
+      const uint32_t first = d.ffirst[f], last = d.flast[fbase + f];
+      const Vec2 e{d.fex[fbase + f], d.fey[fbase + f]};
+      const Frame Pp = parent_frame(d, fbase + f);
+      const TimeBlock tb = time_block_of(d, f, t);
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("" ::"v"(Pt.x), "v"(Pt1.x), "v"(Pt.th), "v"(Pt1.th), "v"(lo), "v"(cnt), "v"(pt), "v"(first), "v"(last),
+                   "v"(e.x), "v"(e.y), "v"(Pp.x), "v"(Pp.y), "v"(Pp.c), "v"(Pp.s), "v"(tb.before), "v"(tb.run_from));
+#endif
+      const ProposalFrames fr = proposal_frames(Pt, Pt1, q);
+      uint32_t slo = lo, len = 0;
+      Vec2 w{0.0, 0.0}, wn{0.0, 0.0};
+      if (tid < nf && first <= t && t < last) {
+        const uint32_t hi = lo + cnt;
+        const uint32_t a = split_readings(d, f, lo, hi, t, tb);
+        w = act(Pp, e);
+        if (t < pt) {  // landmark hangs off a pose that moves
+          wn = act(fr.Pt, act(fr.q, act_inverse(fr.Pt1, w)));
+          len = a - lo;
+        } else {  // poses after t move, seen from them the landmark moves by the inverse
+          wn = act(fr.Pt1, act(fr.qinv, act_inverse(fr.Pt, w)));
+          slo = a;
+          len = hi - a;
+        }
+      }
+      const uint32_t incl = wave_prefix_sums(len);
+      if (tid < nf) {
+        S.seglo[tid] = slo;
+        S.segw[tid][0] = w.x;
+        S.segw[tid][1] = w.y;
+        S.segw[tid][2] = wn.x;
+        S.segw[tid][3] = wn.y;
+        S.segpre[tid + 1] = incl;
+        S.segcur[tid] = make_uint2(incl, slo - (incl - len));
+#ifdef MG_DIAG_RUN_RECORDS
+        S.segt[tid] = len ? d.otime[slo] : 0u;
+#endif
+      }
+      if (tid == 0) S.segpre[0] = 0;
+    }
+    tm.sync();
+    units += S.segpre[nf];
+    MG_STAMP(ts1);
+    MG_PHASE_ADD(S, 1, ts0, ts1);
+    const double sum = eval_ratio<RB>(d, c, S, nf, tid, nthr);
+    MG_STAMP(ts2);
+    MG_PHASE_ADD(S, 2, ts1, ts2);
+    return tm.sum(sum, S);
+  }
+  const ProposalFrames fr = proposal_frames(world_pose(d, c, t), world_pose(d, c, t + 1), q);
   double acc = 0.0;
 #ifdef MG_PHASE_TIMING
   long long tab = clock64();
@@ -1060,34 +1151,6 @@ MG_DEV double eval_state_edge(const Dev& d, uint32_t c, Shared& S, uint32_t t, c
     tab = tc1;
 #endif
   };
-  if (nf <= 64) {
-    // a wavefront's worth of landmarks: the team's first wavefront prepares them all, every landmark a
-    // segment (those without affected readings an empty one), with the prefix sums taken inside the
-    // wavefront -- one barrier instead of three
-    if (tid < 64) {
-      uint32_t len = 0;
-      if (tid < nf) len = prepare(tid, d.ffirst[tid] <= t && t < d.flast[fbase + tid]);
-      uint32_t incl = len;
-#pragma unroll
-      for (int dd = 1; dd < 64; dd <<= 1) {
-        const uint32_t o = __shfl_up(incl, dd);
-        if (tid >= uint32_t(dd)) incl += o;
-      }
-      if (tid < nf) {
-        S.segpre[tid + 1] = incl;
-        S.segcur[tid] = make_uint2(incl, S.seglo[tid] - (incl - len));
-      }
-      if (tid == 0) S.segpre[0] = 0;
-    }
-    tm.sync();
-    units += S.segpre[nf];
-    MG_STAMP(tc0);
-    MG_PHASE_ADD(S, 1, tab, tc0);
-    acc += eval_ratio<RB>(d, c, S, nf, tid, nthr);
-    MG_STAMP(tc1);
-    MG_PHASE_ADD(S, 2, tc0, tc1);
-    return tm.sum(acc, S);
-  }
   if (nf <= segcap) {
     // few landmarks: every one is a segment, those without affected readings an empty one (the
     // readings come in the same order as below, so the sums are the same)
@@ -1939,6 +2002,7 @@ MG_DEV void advance_ahead(DevArgs dp, SharedLds sp, uint32_t c, DriverState& D, 
 #ifdef MG_PHASE_TIMING  // diagnostic build: where the two parties' cycles go, and how the work ahead fares
   long long dg_serial = 0, dg_ahead = 0, dg_wait0 = 0, dg_eval = 0, dg_wait1 = 0, dg_commit = 0;
   long long dg_evals = 0, dg_tried = 0, dg_taken = 0, dg_given_up = 0, dg_wasted = 0, dg_ran_out = 0;
+  long long dg_finish = 0, dg_adopt = 0, dg_afresh = 0;
 #define MG_AHEAD_CLOCK(v) const long long v = clock64()
 #define MG_AHEAD_ADD(acc, a, b) acc += (b) - (a)
 #define MG_AHEAD_COUNT(acc) ++acc
@@ -1978,11 +2042,23 @@ MG_DEV void advance_ahead(DevArgs dp, SharedLds sp, uint32_t c, DriverState& D, 
           commit = true;
         }
       }
+      MG_AHEAD_CLOCK(tf1);
+      MG_AHEAD_ADD(dg_finish, ta0, tf1);
       if (!commit) {
         D.spec_ready = ahead_ok ? 1 : 0;
         if (ahead_ok) MG_AHEAD_COUNT(dg_taken);
+#ifdef MG_PHASE_TIMING
+        const bool adopting = ahead_ok;
+#endif
         ahead_ok = false;
         driver_advance(d, c, S, D, rng);
+#ifdef MG_PHASE_TIMING
+        const long long tf2 = clock64();
+        if (adopting)
+          dg_adopt += tf2 - tf1;
+        else
+          dg_afresh += tf2 - tf1;
+#endif
         if (D.spec_ready) {  // (cannot happen: the driver's next act was checked to be a plain update)
           D.spec_ready = 0;
           D.failed = 1;
@@ -2078,7 +2154,7 @@ MG_DEV void advance_ahead(DevArgs dp, SharedLds sp, uint32_t c, DriverState& D, 
   if (threadIdx.x == 0) {
     S.phase[0] = dg_serial, S.phase[1] = dg_ahead, S.phase[2] = dg_wait0, S.phase[5] = dg_commit;
     S.phase[8] = dg_evals, S.phase[9] = dg_tried, S.phase[10] = dg_taken, S.phase[11] = dg_given_up;
-    S.phase[12] = dg_wasted, S.phase[13] = dg_ran_out, S.phase[14] = 0, S.phase[15] = 0, S.phase[7] = 0;
+    S.phase[12] = dg_wasted, S.phase[13] = dg_ran_out, S.phase[14] = dg_adopt, S.phase[15] = dg_afresh, S.phase[7] = dg_finish;
   }
   if (threadIdx.x == 64) S.phase[3] = dg_eval, S.phase[4] = dg_wait1;
   __syncthreads();

@@ -351,6 +351,11 @@ MG_DEV uint32_t search_by(Load ld, Warm warm, uint32_t n_in, double value) {
     const uint32_t mid_r = open_r ? child_containing(mid, hi - 1) : mid;
     warm(lo, n, mid);
     const double at_mid = ld(mid), at_l = ld(mid_l), at_r = ld(mid_r);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // all three are wanted HERE: left alone, the compiler moves the second level's loads behind the first
+    // comparison (each is used on one side of it only) and the round waits for memory twice
+    asm volatile("" ::"v"(at_mid), "v"(at_l), "v"(at_r));
+#endif
     const double s = origin + at_mid;
     if (uniformly(value < s)) {
       hi = mid;

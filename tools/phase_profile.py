@@ -84,6 +84,9 @@ def plaza(a):
                            (2, "first wavefront: waiting for the evaluation"), (3, "others: evaluation"),
                            (4, "others: waiting for the first wavefront"), (5, "commit")]:
             print(f"  {name:44s} {100.0 * cyc[slot] / whole:6.2f} % of kernel   {cyc[slot] / max(nprop, 1):10.0f} cycles per update")
+        for slot, name in [(7, "  serial step: end of the update (decide, apply)"), (14, "  serial step: on to an update selected ahead"),
+                           (15, "  serial step: on to growth or a fresh selection")]:
+            print(f"  {name:52s} {cyc[slot] / max(nprop, 1):10.0f} cycles per update")
         print(f"  evaluations {int(cyc[8])}: next update selected ahead {int(cyc[9])} ({100.0 * cyc[9] / ev:.1f} %), taken {int(cyc[10])} "
               f"({100.0 * cyc[10] / ev:.1f} %), given up early {int(cyc[11])}, finished but dropped {int(cyc[12])}, "
               f"out of generator words {int(cyc[13])}")
