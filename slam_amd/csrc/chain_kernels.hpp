@@ -2810,6 +2810,164 @@ __global__ void __launch_bounds__(kScanLanes) scan_chain_kernel(ScanArgs a) {
   if (!WRITE && threadIdx.x == 0) a.tot[size_t(c) * a.nseg + seg] = Pose{carry.x, carry.y, carry.th};
 }
 
+// ---- the same scan in ONE pass over memory, for few long chains ------------------------------------
+// The two-pass form above reads every relative pose twice (72 bytes of traffic per pose instead of 48).
+// Here a chain is cut into pieces of kPieceTiles tiles whose scanned poses a workgroup can keep in
+// registers: it scans its piece relative to the piece's start, publishes the piece's total, collects the
+// totals of ALL pieces before it in its chain (they are produced independently of each other, so nobody
+// waits for a chain of hand-overs), composes them in a fixed order -- oldest first, 64 at a time -- and
+// places its poses.  The order of compositions depends on the piece's number only, not on timing, so two
+// rebuilds of the same data give the same bits.  Pieces are handed out by a ticket counter, chain after
+// chain and piece after piece: a workgroup only ever waits for pieces with lower tickets, which are
+// running or done.  The look-back is quadratic in the pieces of a chain (piece p reads p totals), which
+// is nothing against the poses up to kPieceMaxPerChain pieces; longer chains keep the two-pass form.
+constexpr int kPieceTiles = 3;                 // 3072 poses per piece, 12 per lane
+constexpr uint32_t kPieceMaxPerChain = 1024;   // look-back reads at most this many totals per piece
+// A piece's total (x, y, cos, sin, angle) as five 64-bit words, each written and read by one device-wide
+// atomic access of its own.  Before the launch every word holds kPieceEmpty (all ones: a NaN no total
+// contains); a reader takes a total once none of its five words is that any more.  No word waits for
+// another, so nothing needs a cache write-back or invalidation to be ordered: each access is coherent by
+// itself (a release fence of device scope would write back the whole L2 of its XCD, per piece).
+struct alignas(16) PieceSlot {
+  unsigned long long word[5];
+  unsigned long long pad;
+};
+static_assert(sizeof(PieceSlot) == 48, "piece slots are 48 bytes");
+constexpr unsigned long long kPieceEmpty = ~0ull;
+constexpr uint32_t kPieceHeaderBytes = 256;  // the scratch starts with the ticket counter
+
+// a.nseg = pieces per chain, a.seg_len = kPieceTiles tiles; `scratch` = [ticket = 0][chains * nseg slots of kPieceEmpty].
+__global__ void __launch_bounds__(kScanLanes) scan_pieces_kernel(ScanArgs a, unsigned char* scratch) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int K = kScanPerLane, J = kPieceTiles, W = kScanLanes / 64;
+  __shared__ PoseCS stage[J][W];
+  __shared__ PoseCS before_piece;
+  __shared__ uint32_t my_ticket;
+  uint32_t* ticket = reinterpret_cast<uint32_t*>(scratch);
+  PieceSlot* slots = reinterpret_cast<PieceSlot*>(scratch + kPieceHeaderBytes);
+  if (threadIdx.x == 0) my_ticket = atomicAdd(ticket, 1u);
+  __syncthreads();
+  const uint32_t c = my_ticket / a.nseg, piece = my_ticket % a.nseg;
+  const uint32_t tile = uint32_t(kScanLanes) * K;
+  const uint32_t lo = piece * a.seg_len;
+  const uint32_t hi = a.n - lo < a.seg_len ? a.n : lo + a.seg_len;
+  const double* __restrict__ rx = a.relx + size_t(c) * a.rstride;
+  const double* __restrict__ ry = a.rely + size_t(c) * a.rstride;
+  const double* __restrict__ rth = a.relth + size_t(c) * a.rstride;
+  PoseXY* __restrict__ pxy = a.pxy + size_t(c) * a.pstride;
+  double* __restrict__ pth = a.pth + size_t(c) * a.pstride;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const PoseCSOp op;
+  // every load of the piece goes out before anything is computed
+  double x[J][K], y[J][K], th[J][K];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const uint32_t first = lo + j * tile + threadIdx.x * K;
+    if (first + K <= hi) {
+      load4(rx + first, x[j]);
+      load4(ry + first, y[j]);
+      load4(rth + first, th[j]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const bool in = first + k < hi;
+        x[j][k] = in ? rx[first + k] : 0.0;
+        y[j][k] = in ? ry[first + k] : 0.0;
+        th[j][k] = in ? rth[first + k] : 0.0;
+      }
+    }
+  }
+  // the piece relative to its own start: lane runs, wavefront scans, one barrier for all tiles
+  PoseCS excl[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const uint32_t first = lo + j * tile + threadIdx.x * K;
+    PoseCS mine = op.identity();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      // elements past the end are identities: (0, 0, 0) lifts to one
+      const PoseCS v = op.lift(Pose{x[j][k], y[j][k], th[j][k]});
+      mine = (k == 0) ? v : op(mine, v);
+      // the lane's running composition takes the raw element's place (the angle stays in th)
+      x[j][k] = mine.x;
+      y[j][k] = mine.y;
+      th[j][k] = mine.th;
+      // its cosine and sine are needed once more below: for the last element of the run only
+    }
+    (void)first;
+    const PoseCS inc = wave_scan_inclusive(mine, op);
+    if (lane == 63) stage[j][wave] = inc;
+    excl[j] = shfl_up_any(inc, 1);
+    if (lane == 0) excl[j] = op.identity();
+  }
+  __syncthreads();
+  // excl[j] becomes everything of the piece before this lane's run of tile j
+  PoseCS all = op.identity();
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      if (w == wave) excl[j] = op(all, excl[j]);
+      all = op(all, stage[j][w]);
+    }
+  }
+  // `all` is the piece's total: publish it, then collect what lies before the piece
+  PieceSlot* mine_slot = slots + size_t(c) * a.nseg + piece;
+  if (threadIdx.x < 5) {
+    const double part = threadIdx.x == 0 ? all.x : threadIdx.x == 1 ? all.y : threadIdx.x == 2 ? all.c : threadIdx.x == 3 ? all.s : all.th;
+    __hip_atomic_store(&mine_slot->word[threadIdx.x], (unsigned long long)__double_as_longlong(part), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (wave == 0) {
+    PoseCS prefix = op.identity();
+    const PieceSlot* chain_slots = slots + size_t(c) * a.nseg;
+    for (uint32_t w0 = 0; w0 < piece; w0 += 64) {  // pieces w0 .. w0 + 63 of this chain, oldest window first
+      PoseCS v = op.identity();
+      const uint32_t q = w0 + lane;
+      if (q < piece) {
+        const PieceSlot* sl = chain_slots + q;
+        unsigned long long w[5];
+        for (;;) {
+          bool full = true;
+#pragma unroll
+          for (int k = 0; k < 5; ++k) {
+            w[k] = __hip_atomic_load(&sl->word[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            full = full && w[k] != kPieceEmpty;
+          }
+          if (full) break;
+          __builtin_amdgcn_s_sleep(2);
+        }
+        v = PoseCS{__longlong_as_double((long long)w[0]), __longlong_as_double((long long)w[1]), __longlong_as_double((long long)w[2]),
+                   __longlong_as_double((long long)w[3]), __longlong_as_double((long long)w[4])};
+      }
+      const PoseCS inc = wave_scan_inclusive(v, op);  // identities behind the last piece change nothing
+      const PoseCS window = PoseCS{__shfl(inc.x, 63), __shfl(inc.y, 63), __shfl(inc.c, 63), __shfl(inc.s, 63), __shfl(inc.th, 63)};
+      prefix = op(prefix, window);
+    }
+    if (lane == 0) before_piece = prefix;
+  }
+  __syncthreads();
+  const PoseCS P = before_piece;
+  if (piece == 0 && threadIdx.x == 0) {
+    pxy[0] = PoseXY{0.0, 0.0};
+    pth[0] = 0.0;
+  }
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const uint32_t first = lo + j * tile + threadIdx.x * K;
+    const PoseCS start = op(P, excl[j]);  // everything before this lane's run
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if (first + k < hi) {
+        pxy[first + k + 1] = PoseXY{fma(start.c, x[j][k], fma(-start.s, y[j][k], start.x)),
+                                    fma(start.s, x[j][k], fma(start.c, y[j][k], start.y))};
+        pth[first + k + 1] = start.th + th[j][k];
+      }
+    }
+  }
+#endif
+}
+
 // grid = chains.  Exclusive scan of a chain's segment totals, in place: tot[s] becomes the world
 // pose at the start of segment s.
 __global__ void scan_offsets_kernel(uint32_t nseg, Pose* tot) {

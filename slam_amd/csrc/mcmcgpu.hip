@@ -343,7 +343,11 @@ int lay_out(mcmcgpu_handle h, bool with_slack) {
 // handed to a kernel.  All calls on one GPU share the array: calls that overlap there race.
 constexpr uint32_t kStaticScanChains = 4096;  // most chains one mcmcgpu_scan_poses_static call takes
 constexpr uint32_t kStaticScanMaxPoses = 0xFFFF0000u;  // and most relative poses per chain
-constexpr size_t kStaticScratchBytes = (size_t(kScanTargetGroups) + kStaticScanChains) * sizeof(Pose);  // 122 880
+// One MiB: the two-pass scan's segment totals ((1024 + 4096) x 24 bytes at most) or the single-pass scan's
+// ticket and piece slots (256 + 48 bytes per piece of 4096 poses: 64 chains of 1 000 000 poses take 750 KB).
+constexpr size_t kScanScratchBytes = size_t(1) << 20;
+constexpr size_t kStaticScratchBytes = kScanScratchBytes;
+static_assert((size_t(kScanTargetGroups) + kStaticScanChains) * sizeof(Pose) <= kScanScratchBytes, "two-pass totals fit");
 static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
 
 constexpr int kMaxDevices = 64;
@@ -418,6 +422,7 @@ TreeTops plan_tree_tops(const mcmcgpu_ctx* h, uint32_t state_nodes) {
 // data compose in the same order.
 struct ScanPlan {
   uint32_t nseg, seg_len;
+  bool single_pass;  // few long chains: scan_pieces_kernel (nseg = pieces per chain) instead of two passes
 };
 ScanPlan scan_plan(uint32_t chains, uint32_t n) {
   const uint32_t tile = uint32_t(kScanLanes) * kScanPerLane;
@@ -427,14 +432,31 @@ ScanPlan scan_plan(uint32_t chains, uint32_t n) {
   const uint32_t per = (n + nseg - 1) / nseg;
   const uint32_t seg_len = std::max<uint32_t>(tile, (per + tile - 1) / tile * tile);
   nseg = std::max<uint32_t>(1, (n + seg_len - 1) / seg_len);  // no empty segment at the end
-  return ScanPlan{nseg, seg_len};
+  if (nseg > 1) {
+    // chains too few to fill the GPU with whole chains: one pass over memory when the pieces' slots fit
+    // the scratch (the handle's and the static one are the same size, so both entry points plan alike)
+    const uint32_t piece_len = uint32_t(kPieceTiles) * tile;
+    const uint64_t pieces = (uint64_t(n) + piece_len - 1) / piece_len;
+    if (pieces <= kPieceMaxPerChain && kPieceHeaderBytes + uint64_t(chains) * pieces * sizeof(PieceSlot) <= kScanScratchBytes)
+      return ScanPlan{uint32_t(pieces), piece_len, true};
+  }
+  return ScanPlan{nseg, seg_len, false};
 }
 // Segment totals a rebuild of `chains` chains can need: chains * nseg < kScanTargetGroups + chains.
 size_t scan_total_slots(size_t chains) { return kScanTargetGroups + chains; }
 
 // The scan's launches on `stream`; `tot` must hold chains * plan.nseg poses when plan.nseg > 1.
-hipError_t launch_scan(hipStream_t stream, ScanArgs a, uint32_t chains) {
+hipError_t launch_scan(hipStream_t stream, ScanArgs a, uint32_t chains, bool single_pass) {
   if (chains == 0) return hipSuccess;
+  if (single_pass) {  // `tot` is the whole scratch: ticket counter and piece slots, cleared for this launch
+    unsigned char* scratch_bytes = reinterpret_cast<unsigned char*>(a.tot);
+    const size_t used = kPieceHeaderBytes + size_t(chains) * a.nseg * sizeof(PieceSlot);
+    if (hipError_t e = hipMemsetAsync(scratch_bytes, 0, kPieceHeaderBytes, stream); e != hipSuccess) return e;
+    if (hipError_t e = hipMemsetAsync(scratch_bytes + kPieceHeaderBytes, 0xFF, used - kPieceHeaderBytes, stream); e != hipSuccess)
+      return e;
+    hipLaunchKernelGGL(scan_pieces_kernel, dim3(chains * a.nseg), dim3(kScanLanes), 0, stream, a, scratch_bytes);
+    return hipGetLastError();
+  }
   const dim3 grid(a.nseg, chains), lanes(kScanLanes);
   if (a.nseg > 1) {
     hipLaunchKernelGGL(scan_chain_kernel<false>, grid, lanes, 0, stream, a);
@@ -461,7 +483,7 @@ int rebuild_impl(mcmcgpu_handle h, uint32_t first, uint32_t count) {
   a.nseg = plan.nseg;
   a.seg_len = plan.seg_len;
   a.tot = h->scan_tot;
-  HIP_TRY(h, launch_scan(h->stream, a, count));
+  HIP_TRY(h, launch_scan(h->stream, a, count, plan.single_pass));
   // the landmarks' copies of their parent poses follow the rewritten tables
   parent_poses_kernel<<<dim3((d.Fcap + 255) / 256, count), 256, 0, h->stream>>>(d, first);
   HIP_TRY(h, hipGetLastError());
@@ -664,7 +686,7 @@ int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out) {
   ALLOC(h->exch_u, C / 2 + 1);
   ALLOC(h->exch_counts, 2);
   if (d.trace_cap) ALLOC(d.trace, C * d.trace_cap);
-  ALLOC(h->scan_tot, scan_total_slots(C));
+  ALLOC(h->scan_tot, std::max(scan_total_slots(C), kScanScratchBytes / sizeof(Pose) + 1));
   ALLOC(h->seed_stage, C);
   ALLOC(h->reports, size_t(kMaxOwnReports + 1) * C);
   d.max_slices = cfg->max_split_slices;
@@ -1304,7 +1326,7 @@ int mcmcgpu_scan_poses_static(int32_t device, void* stream, uint32_t chains, uin
   void* tot = nullptr;
   HIP_TRY(h, static_scratch_on(device, &tot));
   const ScanPlan plan = scan_plan(chains, n);
-  if (size_t(chains) * plan.nseg * sizeof(Pose) > kStaticScratchBytes)  // cannot happen for chains <= kStaticScanChains
+  if (!plan.single_pass && size_t(chains) * plan.nseg * sizeof(Pose) > kStaticScratchBytes)  // cannot happen for chains <= kStaticScanChains
     return fail(nullptr, MCMCGPU_ERR_CAPACITY, "scan plan exceeds the static scratch");
   ScanArgs a{};
   a.relx = dev_rel_x;
@@ -1318,7 +1340,7 @@ int mcmcgpu_scan_poses_static(int32_t device, void* stream, uint32_t chains, uin
   a.nseg = plan.nseg;
   a.seg_len = plan.seg_len;
   a.tot = static_cast<Pose*>(tot);  // every slot the second pass reads is written by the first: nothing to clear
-  HIP_TRY(h, launch_scan(static_cast<hipStream_t>(stream), a, chains));
+  HIP_TRY(h, launch_scan(static_cast<hipStream_t>(stream), a, chains, plan.single_pass));
   return 0;
 }
 

@@ -92,8 +92,9 @@ def rebuilt_by_handle(T, chains, seed):
 
 
 def test_static_scan_equals_rebuild_on_calls_in_a_row():
-    # 2 chains x 20 000 edges: four segments per chain (the scratch holds their totals); then 3 x 9 000:
-    # two segments; then 2 x 700: one workgroup per chain, the scratch is not touched
+    # 2 chains x 20 000 edges: seven pieces per chain scanned in one pass (the scratch holds the ticket counter
+    # and the pieces' totals); then 3 x 9 000: three pieces; then 2 x 700: one workgroup per chain, the scratch
+    # is not touched
     for T, chains, seed in ((20000, 2, 5), (9000, 3, 6), (700, 2, 7)):
         rel, cum = rebuilt_by_handle(T, chains, seed)
         got = static_scan(rel, pad=3)
