@@ -100,10 +100,11 @@ def test_seed_helpers_match_oracle():
     assert np.array_equal(capi.uniform_sequence(7, 50), oracle_lib.uniform_sequence(7, 50))
 
 
-@pytest.mark.parametrize("uniform_first,serial_program", [(True, 1), (False, 1), (True, 2), (False, 2)])
+@pytest.mark.parametrize("uniform_first,serial_program", [(True, 1), (False, 1), (True, 2), (False, 2), (True, 3), (False, 3)])
 def test_grow_then_run_matches_oracle(uniform_first, serial_program):
-    """multi_mcmc's way: chains grow over the whole data set without updates, then step.  Both builds of the
-    serial part (mcmcgpu_config.serial_program: a called function, or compiled into the kernel)."""
+    """multi_mcmc's way: chains grow over the whole data set without updates, then step.  Every build of the
+    serial part (mcmcgpu_config.serial_program: a called function, compiled into the kernel, compiled in with
+    the first wavefront selecting the next update ahead of time)."""
     p = small_problem()
     seeds = capi.seed_sequence(2024, 4)
     steps = 600
@@ -142,7 +143,7 @@ def test_grow_then_run_matches_oracle(uniform_first, serial_program):
         assert upd[c] == steps
 
 
-@pytest.mark.parametrize("serial_program", [1, 2])
+@pytest.mark.parametrize("serial_program", [1, 2, 3])
 def test_online_with_initialiser_matches_oracle(serial_program):
     """--mcmc-slam's way: initialiser, updates after every timestep, then end steps."""
     p = small_problem(T=300, F=10, k=3, seed=11)
@@ -157,6 +158,34 @@ def test_online_with_initialiser_matches_oracle(serial_program):
     compare_traces(g.trace(0), w.trace(0), abs(w.log_likelihood(0)))
     assert_close(g.log_likelihood()[0], w.log_likelihood(0), REL, "final log likelihood")
     assert_close(g.get_state(0)["cum"], w.state(0)["cum"], REL, "cumulative poses")
+
+
+@pytest.mark.parametrize("lanes,landmarks,k", [(128, 12, 4), (128, 90, 6), (256, 90, 6), (256, 300, 12), (128, 300, 12)])
+def test_selection_ahead_of_time_matches_oracle(lanes, landmarks, k):
+    """serial_program = 3: the first wavefront draws the accept test's uniform and selects and proposes the next
+    update while the other wavefronts evaluate the current one; an accepted update drops what was drawn ahead.
+    Step for step against the oracle with one and with three evaluating wavefronts, with a wavefront's worth
+    of landmarks (set-up inside one wavefront), more (set-up by all, meeting at the evaluating wavefronts' own
+    barrier) and more than a round of segments holds -- online (growth and re-parenting between the updates)
+    and with end steps; the chains accept between a tenth and a third of their proposals, so both outcomes of
+    the work ahead occur hundreds of times."""
+    p = synthetic.make_problem(T=260, n_landmarks=landmarks, k_nearest=k, seed=17 + landmarks, lap_steps=130,
+                               wobble_period=400, range_stddev=2.5, landmark_spread=7.0)
+    seeds = capi.seed_sequence(31 + lanes, 3)
+    w = oracle_world(p, [int(x) for x in seeds], steps_per_timestep=4, end_steps=300)
+    w.replay(p["T"], finish=True)
+    g = gpu_handle(p, seeds, trace_capacity=4096, threads_per_chain=lanes, serial_program=3)
+    g.advance(p["T"], steps_per_timestep=4, end_steps=300)
+    g.sync()  # (raises when a chain has stopped with its error flag set)
+    upd, acc, units = g.counters()
+    for c in range(len(seeds)):
+        compare_traces(g.trace(c), w.trace(c))
+        assert_close(g.log_likelihood()[c], w.log_likelihood(c), REL, f"chain {c} final log likelihood")
+        assert_close(g.get_state(c)["cum"], w.state(c)["cum"], REL, "cumulative poses")
+        assert units[c] == w.units(c), "evaluated-observation counts differ"
+        assert 0.05 * upd[c] < acc[c] < 0.6 * upd[c], f"chain {c}: {acc[c]} of {upd[c]} accepted"
+    full = g.full_log_likelihood()
+    assert_close(g.log_likelihood(), full, 1e-8, "incremental vs from-scratch log likelihood")
 
 
 def test_online_in_pieces_equals_one_call():

@@ -99,6 +99,9 @@ def test_static_scan_equals_rebuild_on_calls_in_a_row():
         rel, cum = rebuilt_by_handle(T, chains, seed)
         got = static_scan(rel, pad=3)
         assert np.array_equal(got, cum), f"T={T}: static scan differs from mcmcgpu_rebuild"
+        # the single-pass scan composes the pieces' totals in an order that depends on the piece only, not on
+        # which workgroup got there first: a second call gives the same bits
+        assert np.array_equal(static_scan(rel, pad=3), got), f"T={T}: two calls on the same data differ"
         ref = sequential_poses(rel[0])
         scale = np.maximum(np.maximum(np.abs(got[0]), np.abs(ref)), 1.0)
         assert np.all(np.abs(got[0] - ref) / scale <= REL), f"T={T}: static scan vs sequential composition"
