@@ -70,8 +70,8 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--rebuild-every", type=int, default=1, help="steps between cumulative-pose rebuilds")
     ap.add_argument("--threads-per-chain", type=int, default=0)
-    ap.add_argument("--serial-program", type=int, default=0, choices=[0, 1, 2],
-                    help="mcmcgpu_config.serial_program: 0 = the library's choice, 1 = called, 2 = compiled into the kernel")
+    ap.add_argument("--serial-program", type=int, default=0, choices=[0, 1, 2, 3],
+                    help="mcmcgpu_config.serial_program: 0 = the library's choice, 1 = called, 2 = compiled into the kernel, 3 = compiled in and selecting ahead")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-plaza", action="store_true")

@@ -104,14 +104,16 @@ def main():
     ap.add_argument("--updates", type=int, default=100)
     ap.add_argument("--timesteps", type=int, default=100_000)
     ap.add_argument("--landmarks", type=int, default=1000)
+    ap.add_argument("--k-nearest", type=int, default=10)
+    ap.add_argument("--range-stddev", type=float, default=1.0)
     ap.add_argument("--threads-per-chain", type=int, default=0)
     ap.add_argument("--serial-program", type=int, default=0, help="mcmcgpu_config.serial_program")
     ap.add_argument("--plaza", default="", help="Plaza1 or Plaza2: the online replay of bench.py's plaza line instead")
     a = ap.parse_args()
     if a.plaza:
         return plaza(a)
-    p = synthetic.make_problem(T=a.timesteps, n_landmarks=a.landmarks)
-    g = capi.McmcGpu(a.chains, p["T"], p["F"], p["N"], threads_per_chain=a.threads_per_chain)
+    p = synthetic.make_problem(T=a.timesteps, n_landmarks=a.landmarks, k_nearest=a.k_nearest, range_stddev=a.range_stddev)
+    g = capi.McmcGpu(a.chains, p["T"], p["F"], p["N"], threads_per_chain=a.threads_per_chain, serial_program=a.serial_program)
     g.upload_problem(p["ctrl_mean"], p["ctrl_std"], p["obs_t"], p["obs_f"], p["obs_mean"], p["obs_std"], p["F"])
     g.init_chains(capi.seed_sequence(12347, a.chains))
     g.load_state(p["true_rel"], p["landmarks"])
