@@ -239,6 +239,8 @@ struct Request {
   uint32_t idx;
   double q[3];
   double new_pll, old_pll;
+  double which;  // the uniform that chose between the two weight trees (:346)
+  int plain;     // the index was found at the first draw (no retry, :349-364)
 };
 struct DriverState {
   int stage;
@@ -1467,6 +1469,8 @@ MG_DEV int begin_update_core(const Dev& d, uint32_t c, Shared& S, DriverState& D
     out.q[2] = 0.0;
     MG_MARK(S, 14);
   }
+  out.which = which;
+  out.plain = retry == 0 ? 1 : 0;
   return BEGIN_OK;
 }
 
@@ -2019,12 +2023,24 @@ MG_DEV void advance_ahead(DevArgs dp, SharedLds sp, uint32_t c, DriverState& D, 
         D.awaiting = 0;
         const uint32_t idx = D.idx;
         const bool accept = decided ? accepted : finish_decide(D, pre, r);
-        if (accept && ahead_ok) {  // drawn ahead on a false premise
-          rng.restore(after_test);
-          ahead_ok = false;
-          MG_AHEAD_COUNT(dg_wasted);
-        }
         finish_apply(d, c, D, pre, r, accept);
+        if (accept && ahead_ok) {
+          // Drawn ahead on a false premise -- which does not always spoil it.  An accepted update changes ONE
+          // weight tree (and that tree's total).  An update drawn ahead on the OTHER tree took its index from
+          // a tree and a total that are what they were, and its proposal from draws that are the same either
+          // way (the generator stood where it stands); all that the accepted update can change for it is the
+          // choice between the trees, :346, which is looked at again with the new totals.
+          bool keep = false;
+          if (D.spec.plain && D.spec.op != D.op) {
+            refresh_totals(d, c, D);
+            keep = ((D.Ws + D.Wf) * D.spec.which < D.Ws) == (D.spec.op == OP_EVAL_STATE);
+          }
+          if (!keep) {
+            rng.restore(after_test);
+            ahead_ok = false;
+            MG_AHEAD_COUNT(dg_wasted);
+          }
+        }
         D.accept = accept ? 1 : 0;
         if (D.pending == PEND_UPDATE) {
           if (accept) ++D.n_acc;
