@@ -247,10 +247,10 @@ int mcmcgpu_rebuild(mcmcgpu_handle h);
  * edges each, component arrays [chains][rel_stride]; out come the cumulative poses, translation
  * dev_cum_xy [chains][cum_stride] as (x, y) pairs (16-byte aligned) and unwrapped angle dev_cum_th
  * [chains][cum_stride], slot k = the pose after k edges (slot 0 = identity), exactly the numbers
- * mcmcgpu_rebuild leaves in a handle's pose tables for the same chains and relative poses.  The
- * segment totals the scan needs when few chains are cut into many workgroups live in a static
- * device array of the library (122 880 bytes per GPU, held until the process ends) instead of
- * allocated memory; the call allocates and frees nothing and runs on `stream` (NULL = the null
+ * mcmcgpu_rebuild leaves in a handle's pose tables for the same chains and relative poses.  What
+ * the scan needs when few chains are cut into many workgroups -- the pieces' totals and the counter
+ * that hands the pieces out -- lives in a static device array of the library (1 MiB per GPU, held
+ * until the process ends) instead of allocated memory; the call allocates and frees nothing and runs on `stream` (NULL = the null
  * stream) of `device`.  Limits: chains <= 4096 and n <= 0xFFFF0000 (MCMCGPU_ERR_CAPACITY beyond),
  * rel_stride >= n, cum_stride >= n + 1.  All calls on one GPU share that array: calls that may
  * overlap on one GPU (different streams or threads) race and must be serialised by the caller.

@@ -1459,9 +1459,15 @@ MG_DEV int begin_update_core(const Dev& d, uint32_t c, Shared& S, DriverState& D
     if (watch()) return BEGIN_GIVEN_UP;
     const size_t fi = size_t(c) * d.Fcap + f;
     const Reading m = parent_reading(d, fi);
+    const Vec2 current{d.fex[fi], d.fey[fi]};
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the landmark's current estimate is asked for WITH its parent reading: one wait for memory, not a
+    // second one after the draws (the compiler leaves a load where its value is used)
+    asm volatile("" ::"v"(m.mu), "v"(m.sd), "v"(current.x), "v"(current.y));
+#endif
     const Vec2 q = propose_landmark(d, rng, m);
     out.new_pll = reading_proposal_log_pdf(m, q);
-    out.old_pll = reading_proposal_log_pdf(m, Vec2{d.fex[fi], d.fey[fi]});
+    out.old_pll = reading_proposal_log_pdf(m, current);
     out.op = OP_EVAL_FEATURE;
     out.idx = f;
     out.q[0] = q.x;
@@ -2931,8 +2937,10 @@ __global__ void __launch_bounds__(kScanLanes) scan_pieces_kernel(ScanArgs a, uns
   PieceSlot* mine_slot = slots + size_t(c) * a.nseg + piece;
   if (threadIdx.x < 5) {
     const double part = threadIdx.x == 0 ? all.x : threadIdx.x == 1 ? all.y : threadIdx.x == 2 ? all.c : threadIdx.x == 3 ? all.s : all.th;
-    __hip_atomic_store(&mine_slot->word[threadIdx.x], (unsigned long long)__double_as_longlong(part), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long bits = (unsigned long long)__double_as_longlong(part);
+    // (input that carries this very NaN through the arithmetic must not look like an empty slot: readers would wait for ever)
+    if (bits == kPieceEmpty) bits = 0x7FF8000000000000ull;
+    __hip_atomic_store(&mine_slot->word[threadIdx.x], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (wave == 0) {
     PoseCS prefix = op.identity();
