@@ -1822,7 +1822,10 @@ MG_DEV void chain_state_load(const Dev& d, uint32_t c, Shared& S, DriverState& D
     D.n_units = 0;
     D.n_state = 0;
     D.n_moved = 0;
-    D.failed = 0;
+    // a chain that has stopped (edge selection did not terminate: an infinite weight, where the reference
+    // prints "stuck in ... select loop" for ever, mcmc_slam.hpp:350-354) stays stopped: a later launch must
+    // not spend its 65 536 redraws again (a replay queues one launch per timestep)
+    D.failed = d.errflag[c];
     D.w_dirty = 1;
     D.sw_top = D.fw_top = 0;
     D.sw_shift = D.fw_shift = 0;
