@@ -595,7 +595,7 @@ def main():
         }]
         if rebuilds:
             other_kernels.append({
-                "kernel": "scan_chain_kernel (mcmcgpu_rebuild)", "ms": rebuild_ms, "launches": rebuilds,
+                "kernel": "scan_chain_kernel / scan_pieces_kernel (mcmcgpu_rebuild)", "ms": rebuild_ms, "launches": rebuilds,
                 "bytes_per_launch": scan_bytes, "achieved": scan_bytes / (rebuild_ms * 1e-3) / 1e9 if rebuild_ms > 0 else 0.0,
                 "frac": scan_bytes / (rebuild_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if rebuild_ms > 0 else 0.0,
             })
