@@ -271,6 +271,15 @@ struct DriverState {
   Request spec;
 };
 
+// An update as far as its accept test is concerned (mcmc_slam.hpp:385-408).
+struct TestInputs {
+  int is_state, use_weight;
+  double new_pll, old_pll;
+  double beta;        // the chain's inverse temperature
+  double weight_sum;  // both trees' totals (:400-401), while the update is in flight
+  double u;           // the uniform of :408 (nothing else draws between a proposal and that uniform)
+};
+
 // A request as the SPEC variant's first wavefront posts it for the others.
 struct Posted {
   int op;
@@ -278,6 +287,7 @@ struct Posted {
   double q[3];
   uint32_t Tcur, nf;
   uint32_t join;  // with a commit: every wavefront meets again when the pose table is moved
+  TestInputs test;  // with an evaluation: what its accept test needs besides the evaluation's result
 };
 
 struct Shared {
@@ -304,6 +314,11 @@ struct Shared {
   uint32_t tail_arrivals, eval_arrived;
   unsigned long long eval_units;
   Posted post[2];
+  // ... and the accept test as the last of them decides it: the number of the evaluation it belongs to
+  // (written last), the decision, the new edge weight, the evaluation's sum
+  uint32_t verdict_of;
+  int verdict_accepted;
+  double verdict_new_weight, verdict_sum;
 };
 
 // Separately compiled pieces (see advance_kernel) take the kernel-argument block and the chain's
@@ -1574,9 +1589,9 @@ MG_DEV bool driver_finish_update(const Dev& d, uint32_t c, DriverState& D, R& rn
   return accept;
 }
 
-// driver_finish_update in three parts, for a caller that has something to do between them (advance_kernel's
-// SPEC variant): what does not need the evaluation's result -- the two weights, the normaliser, the
-// uniform of the accept test (:389-401, :408: nothing else draws between the proposal and that uniform);
+// driver_finish_update in three parts (advance_kernel's SPEC variant, where the accept test is prepared
+// and decided by a wavefront that does not hold the driver's state): what does not need the evaluation's
+// result -- the two weights, the normaliser times the uniform of the accept test (:389-401, :408);
 // the decision once the result is there; and what the decision changes.  Same operations on the same
 // numbers as the one-piece form.
 struct FinishPrepared {
@@ -1584,58 +1599,42 @@ struct FinishPrepared {
   double log_weight_change;  // new_log_weight - old_log_weight
   double bar_factor;         // normaliser x the accept test's uniform
 };
-template <class R>
-MG_DEV FinishPrepared finish_prepare(const Dev& d, uint32_t c, DriverState& D, R& rng) {
-  const bool is_state = (D.op == OP_EVAL_STATE);
-  const double dim = is_state ? 3.0 : 2.0;
-  const double new_log_weight = log(dim) - D.new_pll / dim;
-  const double old_log_weight = log(dim) - D.old_pll / dim;
-  double new_weight, old_weight;
 #if defined(__HIP_DEVICE_COMPILE__)
-  if (R::kWave) {
-    const double e = exp((threadIdx.x & 63u) == 1 ? old_log_weight : new_log_weight);
-    new_weight = wt::readlane_f64(e, 0);
-    old_weight = wt::readlane_f64(e, 1);
-  } else
-#endif
-  {
-    new_weight = exp(new_log_weight);
-    old_weight = D.use_weight ? exp(old_log_weight) : 0.0;
-  }
+MG_DEV FinishPrepared finish_prepare(const TestInputs& in) {  // by a whole wavefront on the same data
+  const double dim = in.is_state ? 3.0 : 2.0;
+  const double new_log_weight = log(dim) - in.new_pll / dim;
+  const double old_log_weight = log(dim) - in.old_pll / dim;
+  const double e = exp((threadIdx.x & 63u) == 1 ? old_log_weight : new_log_weight);
+  const double new_weight = wt::readlane_f64(e, 0), old_weight = wt::readlane_f64(e, 1);
   double normaliser = 1.0;
-  if (D.use_weight) {
-    refresh_totals(d, c, D);
-    const double weight_sum = D.Ws + D.Wf;
-    normaliser += (new_weight - old_weight) / weight_sum;
-  }
-  return FinishPrepared{new_weight, new_log_weight - old_log_weight, normaliser * rng.uniform()};
+  if (in.use_weight) normaliser += (new_weight - old_weight) / in.weight_sum;
+  return FinishPrepared{new_weight, new_log_weight - old_log_weight, normaliser * in.u};
 }
-MG_DEV bool finish_decide(const DriverState& D, const FinishPrepared& pre, double obs_ratio) {
-  const bool is_state = (D.op == OP_EVAL_STATE);
-  const double proposal_log_ratio = D.new_pll - D.old_pll;
-  const double tempered = is_state ? (D.new_pll - D.old_pll) + D.beta * obs_ratio : D.beta * obs_ratio;
+#endif
+MG_DEV bool finish_decide(const TestInputs& in, const FinishPrepared& pre, double obs_ratio) {
+  const double proposal_log_ratio = in.new_pll - in.old_pll;
+  const double tempered = in.is_state ? (in.new_pll - in.old_pll) + in.beta * obs_ratio : in.beta * obs_ratio;
   double accept_log_ratio = tempered - proposal_log_ratio;
-  if (D.use_weight) accept_log_ratio += pre.log_weight_change;
+  if (in.use_weight) accept_log_ratio += pre.log_weight_change;
 #ifdef MG_DIAG_REJECT_ALL
   return (pre.bar_factor < exp(accept_log_ratio)) && false;
 #else
   return pre.bar_factor < exp(accept_log_ratio);
 #endif
 }
-MG_DEV void finish_apply(const Dev& d, uint32_t c, DriverState& D, const FinishPrepared& pre, double obs_ratio,
-                         bool accept) {
+MG_DEV void finish_apply(const Dev& d, uint32_t c, DriverState& D, double new_weight, double obs_ratio, bool accept) {
   const bool is_state = (D.op == OP_EVAL_STATE);
   const double log_ratio = is_state ? (D.new_pll - D.old_pll) + obs_ratio : obs_ratio;
   if (accept) {
     if (is_state) {
       D.llc += D.new_pll - D.old_pll;
       d.clp[size_t(c) * d.Tcap + D.idx] = D.new_pll;
-      wt::set(state_tree(d, c, D), D.Tcur, D.idx, pre.new_weight);
+      wt::set(state_tree(d, c, D), D.Tcur, D.idx, new_weight);
     } else {
       const size_t fi = size_t(c) * d.Fcap + D.idx;
       d.fex[fi] = D.q[0];
       d.fey[fi] = D.q[1];
-      wt::set(landmark_tree(d, c, D), D.nf, D.idx, pre.new_weight);
+      wt::set(landmark_tree(d, c, D), D.nf, D.idx, new_weight);
     }
     D.w_dirty = 1;
     D.ll += log_ratio;
@@ -1975,43 +1974,51 @@ MG_PIECE void piece_commit(DevArgs dp, uint32_t c, uint32_t idx, double qx, doub
 
 #if defined(__HIP_DEVICE_COMPILE__)
 // The first wavefront's view of the evaluation that runs beside it (advance_ahead): asked between the
-// parts of the selection drawn ahead, it looks whether the evaluation has come back, decides the accept
-// test when it has, and says "give up" when the update was accepted.
+// parts of the selection drawn ahead, it looks whether the update in flight has been decided, and says
+// "give up" when it was accepted.
 struct EvalWatch {
   Shared& S;
-  const DriverState& D;
-  const FinishPrepared& pre;
-  uint32_t arrivals_due;  // S.eval_arrived once every evaluating wavefront has left its sum
+  uint32_t number;  // of the evaluation in flight
   bool decided = false, accepted = false;
   MG_DEV bool operator()() {
     if (decided) return false;
-    if (__hip_atomic_load(&S.eval_arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != arrivals_due) return false;
+    if (__hip_atomic_load(&S.verdict_of, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != number) return false;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     decided = true;
-    accepted = finish_decide(D, pre, tail_waves_sum(S));
+    accepted = S.verdict_accepted != 0;
     return accepted;
   }
 };
 
 // The loop of advance_kernel's SPEC variant (see there).  Two hardware barriers per update: one after
-// the request is posted, one when both the evaluation and the work ahead are over.  The pose table behind
-// an accepted state edge is moved by the other wavefronts alone while the first one already selects the
-// next update (selection and proposal read weights, controls and landmark estimates, never a pose) --
-// unless the driver's next act is growth, which does read poses and waits for them.
+// the request is posted, one when both the evaluation and the work ahead are over.
+//   * The first wavefront posts a request together with what its accept test needs -- the proposal's two
+//     log densities, the weight totals, and the test's uniform, which it draws right behind the proposal
+//     (nothing else draws between the two, mcmc_slam.hpp:375-408) -- and then selects and proposes the
+//     NEXT update as it will be if this one is rejected.
+//   * The other wavefronts evaluate.  The last of them has nothing to do while the first of them sets the
+//     segments up: it prepares the accept test meanwhile (the two edge weights, the normaliser), and when
+//     every wavefront has left its sum it decides the test and leaves the verdict for the first wavefront,
+//     which by then only has to apply it.
+//   * The pose table behind an accepted state edge is moved by the evaluating wavefronts alone while the
+//     first one already selects the next update (selection and proposal read weights, controls and
+//     landmark estimates, never a pose) -- unless the driver's next act is growth, which does read poses
+//     and waits for them.
 template <bool RB>
 MG_DEV void advance_ahead(DevArgs dp, SharedLds sp, uint32_t c, DriverState& D, WaveRng& rng) {
   const Dev& d = *(const Dev*)dp;
   Shared& S = *(Shared*)sp;
   const bool first_wave = threadIdx.x < 64;
   const uint32_t tail_waves = (blockDim.x >> 6) - 1u;
+  const bool last_wave = (threadIdx.x >> 6) == tail_waves;
   TailWaves tail(&S.tail_arrivals);
   uint32_t evals = 0;  // evaluations started so far
   uint32_t round = 0;  // requests posted so far: they alternate between two slots
-  // the first wavefront's: the update in flight as far as it is prepared and decided
-  FinishPrepared pre{0.0, 0.0, 0.0};
-  bool decided = false, accepted = false, ahead_ok = false;
+  // the first wavefront's: the request selected ahead, with its accept test's uniform; the generator as it
+  // stood behind the uniform of the update in flight
+  bool ahead_ok = false;
+  double ahead_u = 0.0;
   WaveRng::Mark after_test = rng.mark();
-  double r = 0.0;
 #ifdef MG_PHASE_TIMING  // diagnostic build: where the two parties' cycles go, and how the work ahead fares
   long long dg_serial = 0, dg_ahead = 0, dg_wait0 = 0, dg_eval = 0, dg_wait1 = 0, dg_commit = 0;
   long long dg_evals = 0, dg_tried = 0, dg_taken = 0, dg_given_up = 0, dg_wasted = 0, dg_ran_out = 0;
@@ -2028,11 +2035,11 @@ MG_DEV void advance_ahead(DevArgs dp, SharedLds sp, uint32_t c, DriverState& D, 
     MG_AHEAD_CLOCK(ta0);
     if (first_wave) {
       bool commit = false;
-      if (D.awaiting) {  // the end of the update whose evaluation is back: step_with's first half
+      if (D.awaiting) {  // the end of the update whose evaluation and verdict are back: step_with's first half
         D.awaiting = 0;
         const uint32_t idx = D.idx;
-        const bool accept = decided ? accepted : finish_decide(D, pre, r);
-        finish_apply(d, c, D, pre, r, accept);
+        const bool accept = S.verdict_accepted != 0;
+        finish_apply(d, c, D, S.verdict_new_weight, S.verdict_sum, accept);
         if (accept && ahead_ok) {
           // Drawn ahead on a false premise -- which does not always spoil it.  An accepted update changes ONE
           // weight tree (and that tree's total).  An update drawn ahead on the OTHER tree took its index from
@@ -2069,14 +2076,30 @@ MG_DEV void advance_ahead(DevArgs dp, SharedLds sp, uint32_t c, DriverState& D, 
       }
       MG_AHEAD_CLOCK(tf1);
       MG_AHEAD_ADD(dg_finish, ta0, tf1);
+      TestInputs test{0, 0, 0.0, 0.0, 1.0, 1.0, 0.0};
       if (!commit) {
+        const bool adopting = ahead_ok;
         D.spec_ready = ahead_ok ? 1 : 0;
         if (ahead_ok) MG_AHEAD_COUNT(dg_taken);
-#ifdef MG_PHASE_TIMING
-        const bool adopting = ahead_ok;
-#endif
         ahead_ok = false;
         driver_advance(d, c, S, D, rng);
+        if (D.spec_ready) {  // (cannot happen: the driver's next act was checked to be a plain update)
+          D.spec_ready = 0;
+          D.failed = 1;
+        }
+        if (D.op == OP_EVAL_STATE || D.op == OP_EVAL_FEATURE) {
+          D.awaiting = 1;
+          // the accept test's uniform: drawn behind the proposal -- with it when the request was selected ahead
+          test.u = adopting ? ahead_u : rng.uniform();
+          after_test = rng.mark();
+          if (D.use_weight) refresh_totals(d, c, D);
+          test.is_state = D.op == OP_EVAL_STATE ? 1 : 0;
+          test.use_weight = D.use_weight;
+          test.new_pll = D.new_pll;
+          test.old_pll = D.old_pll;
+          test.beta = D.beta;
+          test.weight_sum = D.Ws + D.Wf;
+        }
 #ifdef MG_PHASE_TIMING
         const long long tf2 = clock64();
         if (adopting)
@@ -2084,11 +2107,6 @@ MG_DEV void advance_ahead(DevArgs dp, SharedLds sp, uint32_t c, DriverState& D, 
         else
           dg_afresh += tf2 - tf1;
 #endif
-        if (D.spec_ready) {  // (cannot happen: the driver's next act was checked to be a plain update)
-          D.spec_ready = 0;
-          D.failed = 1;
-        }
-        if (D.op == OP_EVAL_STATE || D.op == OP_EVAL_FEATURE) D.awaiting = 1;
       }
       if (threadIdx.x == 0) {  // the request, where the other wavefronts find it
         Posted& post = S.post[round & 1u];
@@ -2101,6 +2119,7 @@ MG_DEV void advance_ahead(DevArgs dp, SharedLds sp, uint32_t c, DriverState& D, 
         post.nf = D.nf;
         // a commit: does the driver go on to something that reads the pose table?
         post.join = !(D.stage == ST_STEPS && D.steps_left > 0) && !(D.stage == ST_END_STEPS && D.end_left > 0);
+        post.test = test;
       }
     }
     __syncthreads();
@@ -2115,12 +2134,7 @@ MG_DEV void advance_ahead(DevArgs dp, SharedLds sp, uint32_t c, DriverState& D, 
     const uint32_t Tcur = post.Tcur, nf = post.nf;
     if (op == OP_COMMIT) {  // the state edge just accepted: the other wavefronts move the pose table
       const uint32_t join = post.join;
-      if (tail_waves == 0) {
-        WholeBlock everyone;
-        commit_body(dp, c, idx, qx, qy, qth, Tcur, nf, everyone);
-      } else if (!first_wave) {
-        commit_body(dp, c, idx, qx, qy, qth, Tcur, nf, tail);
-      }
+      if (!first_wave) commit_body(dp, c, idx, qx, qy, qth, Tcur, nf, tail);
       D.n_moved += Tcur - idx;
       if (join) __syncthreads();
       MG_AHEAD_CLOCK(tc1);
@@ -2130,33 +2144,48 @@ MG_DEV void advance_ahead(DevArgs dp, SharedLds sp, uint32_t c, DriverState& D, 
     ++evals;
     MG_AHEAD_COUNT(dg_evals);
     if (first_wave) {
-      pre = finish_prepare(d, c, D, rng);
-      after_test = rng.mark();
-      decided = false;
       ahead_ok = false;
       // the driver's next act is another plain update: the one in flight is one, and more are due
       const bool more = (D.stage == ST_STEPS && D.steps_left > 0) || (D.stage == ST_END_STEPS && D.end_left > 0);
       if (D.pending == PEND_UPDATE && more && !D.failed) {
-        EvalWatch watch{S, D, pre, evals * tail_waves};
+        EvalWatch watch{S, evals};
         rng.ahead = true;
         rng.ran_out = false;
         MG_AHEAD_COUNT(dg_tried);
         const int st = begin_update_core(d, c, S, D, rng, D.spec, watch);
+        if (st == BEGIN_OK) ahead_u = rng.uniform();  // its accept test's uniform, behind its proposal
         ahead_ok = st == BEGIN_OK && !rng.ran_out;
         if (st == BEGIN_GIVEN_UP) MG_AHEAD_COUNT(dg_given_up);
         if (rng.ran_out) MG_AHEAD_COUNT(dg_ran_out);
         rng.ahead = false;
         rng.ran_out = false;
-        decided = watch.decided;
-        accepted = watch.accepted;
         if (!ahead_ok) rng.restore(after_test);
       }
       MG_AHEAD_CLOCK(tb1);
       MG_AHEAD_ADD(dg_ahead, ta1, tb1);
     } else {
+      // the accept test as far as it can be prepared: by the last evaluating wavefront, which would
+      // otherwise wait for the first of them to set the segments up
+      FinishPrepared pre{0.0, 0.0, 0.0};
+      if (last_wave) pre = finish_prepare(post.test);
       unsigned long long units;
       inline_eval<RB>(dp, sp, c, op, idx, qx, qy, qth, nf, units, tail);  // leaves the sums in S.red
       if (tail.tid() == 0) S.eval_units = units;
+      if (last_wave) {  // ... and its decision, once every wavefront's sum is there
+        const uint32_t due = evals * tail_waves;
+        while (__hip_atomic_load(&S.eval_arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != due) {
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const double sum = tail_waves_sum(S);
+        const bool accept = finish_decide(post.test, pre, sum);
+        if ((threadIdx.x & 63u) == 0) {
+          S.verdict_accepted = accept ? 1 : 0;
+          S.verdict_new_weight = pre.new_weight;
+          S.verdict_sum = sum;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __hip_atomic_store(&S.verdict_of, evals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
       MG_AHEAD_CLOCK(tb1);
       MG_AHEAD_ADD(dg_eval, ta1, tb1);
     }
@@ -2167,7 +2196,6 @@ MG_DEV void advance_ahead(DevArgs dp, SharedLds sp, uint32_t c, DriverState& D, 
       MG_AHEAD_ADD(dg_wait0, tw0, tw1);
     else
       MG_AHEAD_ADD(dg_wait1, tw0, tw1);
-    r = tail_waves_sum(S);
     D.n_units += S.eval_units;
     if (op == OP_EVAL_STATE) ++D.n_state;
   }
@@ -2255,6 +2283,7 @@ __global__ void __launch_bounds__(SOLO ? 256 : 1024) advance_kernel(Dev d, uint3
   if (threadIdx.x == 0) {
     S.tail_arrivals = 0;
     S.eval_arrived = 0;
+    S.verdict_of = 0;
   }
   __syncthreads();
   MG_STAMP(tk0);
