@@ -116,6 +116,8 @@ struct Dev {
   // null on a range-only handle): a copy of what foff[f] + fpar indexes, so that a landmark proposal
   // finds its distribution in one load instead of three dependent ones
   double *fpmu, *fpsd, *fpbmu, *fpbsd;
+  double *fplsd, *fplbsd;  // [C][Fcap] log of fpsd / fpbsd, taken when the copy is (fplbsd null on a range-only handle)
+
   uint32_t* flast;              // [C][Fcap]   timestep of the latest reading seen
   uint32_t* nf;                 // [C]         landmarks known
   double* ll;                   // [C]         chain log likelihood
@@ -1301,6 +1303,8 @@ MG_DEV Reading load_reading(const Dev& d, uint32_t o) {
   m.bearing = d.obear != nullptr;
   m.bmu = m.bearing ? d.obear[o] : 0.0;
   m.bsd = m.bearing ? d.obsd[o] : 1.0;
+  m.log_sd = log(m.sd);
+  m.log_bsd = m.bearing ? log(m.bsd) : 0.0;
   return m;
 }
 
@@ -1312,14 +1316,18 @@ MG_DEV Reading parent_reading(const Dev& d, size_t fi) {
   m.bearing = d.obear != nullptr;
   m.bmu = m.bearing ? d.fpbmu[fi] : 0.0;
   m.bsd = m.bearing ? d.fpbsd[fi] : 1.0;
+  m.log_sd = d.fplsd[fi];
+  m.log_bsd = m.bearing ? d.fplbsd[fi] : 0.0;
   return m;
 }
 MG_DEV void keep_parent_reading(const Dev& d, size_t fi, const Reading& m) {
   d.fpmu[fi] = m.mu;
   d.fpsd[fi] = m.sd;
+  d.fplsd[fi] = m.log_sd;
   if (m.bearing) {
     d.fpbmu[fi] = m.bmu;
     d.fpbsd[fi] = m.bsd;
+    d.fplbsd[fi] = m.log_bsd;
   }
 }
 

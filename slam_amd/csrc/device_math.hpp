@@ -143,17 +143,18 @@ MG_DEV double control_log_pdf(const double mu[3], const double sd[3], double log
 MG_DEV double control_log_det(double sd0, double sd1, double sd2) { return log(sd0) + log(sd1) + log(sd2); }
 
 // ---- range-only observation model ------------------------------------------
-MG_DEV double range_log_pdf(double mu, double sd, double r) {
+// (log_sd = log(sd): a reading's sigma does not change, so its logarithm is taken once and kept)
+MG_DEV double range_log_pdf(double mu, double sd, double log_sd, double r) {
   const double z = (r - mu) / sd;
   const double log_root_two_pi = 0.5 * log(2 * kPi);
-  return -0.5 * (z * z) - log_root_two_pi - log(sd);
+  return -0.5 * (z * z) - log_root_two_pi - log_sd;
 }
 
 MG_DEV double vec_norm(const Vec2& v) { return sqrt(v.x * v.x + v.y * v.y); }
 
 // log pdf of the landmark proposal (range normal x uniform direction)
-MG_DEV double range_proposal_log_pdf(double mu, double sd, const Vec2& p) {
-  return range_log_pdf(mu, sd, vec_norm(p)) - log(2 * kPi);
+MG_DEV double range_proposal_log_pdf(double mu, double sd, double log_sd, const Vec2& p) {
+  return range_log_pdf(mu, sd, log_sd, vec_norm(p)) - log(2 * kPi);
 }
 
 MG_DEV Vec2 polar(double dist, double dir) {
@@ -171,20 +172,21 @@ struct Reading {
   double mu, sd;    // range
   double bmu, bsd;  // bearing
   bool bearing;
+  double log_sd, log_bsd;  // log(sd), log(bsd): the same library call on the same bits, taken when the reading is loaded
 };
 
 // log_likelihood(observe(p)), src/utility/random.hpp:103-121
 MG_DEV double reading_log_pdf(const Reading& m, const Vec2& p) {
-  if (!m.bearing) return range_log_pdf(m.mu, m.sd, vec_norm(p));
+  if (!m.bearing) return range_log_pdf(m.mu, m.sd, m.log_sd, vec_norm(p));
   const double log_root_two_pi = 0.5 * log(2 * kPi);
   const double x0 = (vec_norm(p) - m.mu) / m.sd;
   const double x1 = wrap_angle(atan2(p.y, p.x) - m.bmu) / m.bsd;
-  return -0.5 * (x0 * x0 + x1 * x1) - 2 * log_root_two_pi - (log(m.sd) + log(m.bsd));
+  return -0.5 * (x0 * x0 + x1 * x1) - 2 * log_root_two_pi - (m.log_sd + m.log_bsd);
 }
 
 // proposal_dist::log_likelihood: :166-169 (range only: a uniform direction on top) and :90-92
 MG_DEV double reading_proposal_log_pdf(const Reading& m, const Vec2& p) {
-  return m.bearing ? reading_log_pdf(m, p) : range_log_pdf(m.mu, m.sd, vec_norm(p)) - log(2 * kPi);
+  return m.bearing ? reading_log_pdf(m, p) : range_log_pdf(m.mu, m.sd, m.log_sd, vec_norm(p)) - log(2 * kPi);
 }
 
 MG_DEV double edge_weight_from_log_pdf(double log_pdf, double dim, double* log_weight) {

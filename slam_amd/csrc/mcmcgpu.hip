@@ -662,9 +662,11 @@ int mcmcgpu_create(const mcmcgpu_config* cfg, mcmcgpu_handle* out) {
   ALLOC(d.fps, C * d.Fcap);
   ALLOC(d.fpmu, C * d.Fcap);
   ALLOC(d.fpsd, C * d.Fcap);
+  ALLOC(d.fplsd, C * d.Fcap);
   if (cfg->range_bearing) {
     ALLOC(d.fpbmu, C * d.Fcap);
     ALLOC(d.fpbsd, C * d.Fcap);
+    ALLOC(d.fplbsd, C * d.Fcap);
   }
   ALLOC(d.flast, C * d.Fcap);
   ALLOC(d.nf, C);
