@@ -244,6 +244,20 @@ struct Request {
   double which;  // the uniform that chose between the two weight trees (:346)
   int plain;     // the index was found at the first draw (no retry, :349-364)
 };
+// A landmark proposal's readings fetched while the proposal is still being drawn (one wavefront per chain,
+// range-only readings, a list of at most 64): lane L holds reading L of the landmark's list and the pose it
+// was taken at, every lane the landmark's parent frame and current estimate.  The evaluation is then
+// arithmetic on registers and one reduction -- no set-up, no LDS tables, no memory round trip after the
+// proposal (three in a row otherwise: landmark, records, poses).
+constexpr int kDirtyStates = 1, kDirtyLandmarks = 2;
+struct ListAhead {
+  int valid;
+  uint32_t count;
+  Frame parent;
+  Vec2 current;    // the landmark's estimate, relative to its parent pose
+  double mu, k;    // this lane's reading: measured range, 1 / (2 sigma^2)
+  PoseXY pose;     // where it was taken
+};
 struct DriverState {
   int stage;
   uint32_t tn, upto, arr, arr_end, steps_left, steps_per_ts, end_left, end_done, end_inflight;
@@ -252,8 +266,8 @@ struct DriverState {
   double ll;
   double beta;    // inverse temperature of this chain (1 = the reference's sampler)
   double llc;     // control-model part of ll
-  double Ws, Wf;  // weight totals, valid while !w_dirty
-  int w_dirty;
+  double Ws, Wf;  // weight totals of the two trees
+  int w_dirty;    // which of them are out of date: kDirtyStates | kDirtyLandmarks
   // LDS copies of the tops of the two weight trees (advance_kernel, dynamic LDS): byte address in
   // LDS of each copy (0 = none) and the stride 2^shift of the nodes it holds
   uint32_t sw_top, fw_top, sw_shift, fw_shift;
@@ -271,6 +285,7 @@ struct DriverState {
   // rejected (advance_kernel's SPEC variant); driver_begin_update takes it instead of drawing
   int spec_ready;
   Request spec;
+  ListAhead list;  // with a landmark request posted by driver_begin_update: see ListAhead
 };
 
 // An update as far as its accept test is concerned (mcmc_slam.hpp:385-408).
@@ -1398,7 +1413,7 @@ MG_DEV void driver_add_state_edge(const Dev& d, uint32_t c, DriverState& D) {
   const double lp = control_log_pdf(mu, sd, ld, est);
   d.clp[ri] = lp;
   wt::push_back(state_tree(d, c, D), t, edge_weight_from_log_pdf(lp, 3.0, nullptr));
-  D.w_dirty = 1;
+  D.w_dirty |= kDirtyStates;
   D.ll += lp;
   D.llc += lp;
   D.Tcur = t + 1;
@@ -1409,8 +1424,8 @@ MG_DEV void driver_add_state_edge(const Dev& d, uint32_t c, DriverState& D) {
 // gives bit-identical values.
 MG_DEV void refresh_totals(const Dev& d, uint32_t c, DriverState& D) {
   if (!D.w_dirty) return;
-  D.Ws = wt::total(state_tree(d, c, D), D.Tcur);
-  D.Wf = wt::total(landmark_tree(d, c, D), D.nf);
+  if (D.w_dirty & kDirtyStates) D.Ws = wt::total(state_tree(d, c, D), D.Tcur);
+  if (D.w_dirty & kDirtyLandmarks) D.Wf = wt::total(landmark_tree(d, c, D), D.nf);
   D.w_dirty = 0;
 }
 
@@ -1468,6 +1483,7 @@ MG_DEV int begin_update_core(const Dev& d, uint32_t c, Shared& S, DriverState& D
     out.new_pll = control_log_pdf(mu, sd, ld, q);
     out.old_pll = old_pll;
     MG_MARK(S, 13);
+    D.list.valid = 0;
     out.op = OP_EVAL_STATE;
     out.idx = t;
     out.q[0] = q.x;
@@ -1484,11 +1500,50 @@ MG_DEV int begin_update_core(const Dev& d, uint32_t c, Shared& S, DriverState& D
     const Reading m = parent_reading(d, fi);
     const Vec2 current{d.fex[fi], d.fey[fi]};
 #if defined(__HIP_DEVICE_COMPILE__)
+    // One wavefront per chain (it runs this program AND the evaluation): what the evaluation of this
+    // proposal will read is asked for now, so that its three memory round trips pass while the proposal
+    // is drawn -- the landmark's list and parent frame with the parent reading, ...
+    const bool fetch_ahead = R::kWave && blockDim.x == 64 && d.obear == nullptr;
+    uint32_t list_lo = 0, list_count = 0;
+    Frame list_parent{0.0, 0.0, 1.0, 0.0};
+    if (fetch_ahead) {
+      list_lo = d.foff[f];
+      list_count = d.fcnt[fi];
+      list_parent = parent_frame(d, fi);
+    }
     // the landmark's current estimate is asked for WITH its parent reading: one wait for memory, not a
     // second one after the draws (the compiler leaves a load where its value is used)
-    asm volatile("" ::"v"(m.mu), "v"(m.sd), "v"(current.x), "v"(current.y));
+    asm volatile("" ::"v"(m.mu), "v"(m.sd), "v"(current.x), "v"(current.y), "v"(list_lo), "v"(list_count), "v"(list_parent.x),
+                 "v"(list_parent.y), "v"(list_parent.c), "v"(list_parent.s));
+    // ... lane L's reading of the list before the draws, ...
+    const bool list_fits = fetch_ahead && list_count <= 64u;
+    const uint32_t lane = threadIdx.x & 63u;
+    StreamRec list_rec{0.0, 0u};
+    double list_k = 0.5 * d.usig_inv * d.usig_inv;
+    if (list_fits) {
+      const uint32_t o = list_lo + (lane < list_count ? lane : 0u);
+      list_rec = d.osr[o];
+      if (!(d.usig_inv > 0.0)) {
+        const double isd = d.oisd[o];
+        list_k = 0.5 * isd * isd;
+      }
+    }
 #endif
     const Vec2 q = propose_landmark(d, rng, m);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // ... and the pose it was taken at between the draws and the proposal's densities
+    D.list.valid = 0;
+    if (list_fits) {
+      asm volatile("" ::"v"(list_rec.t), "v"(list_rec.mu), "v"(list_k));
+      D.list.pose = d.pxy[size_t(c) * (d.Tcap + 1) + list_rec.t];
+      D.list.valid = 1;
+      D.list.count = list_count;
+      D.list.parent = list_parent;
+      D.list.current = current;
+      D.list.mu = list_rec.mu;
+      D.list.k = list_k;
+    }
+#endif
     out.new_pll = reading_proposal_log_pdf(m, q);
     out.old_pll = reading_proposal_log_pdf(m, current);
     out.op = OP_EVAL_FEATURE;
@@ -1543,8 +1598,9 @@ MG_DEV bool driver_finish_update(const Dev& d, uint32_t c, DriverState& D, R& rn
   const double log_ratio = is_state ? (D.new_pll - D.old_pll) + obs_ratio : obs_ratio;
   // the three exponentials of the step (:389, :397, :408) have their arguments ready together: a
   // wavefront takes one each in three lanes, one lane takes them one after the other; same values
-  const double new_log_weight = log(dim) - D.new_pll / dim;  // edge_log_weight, :160-162
-  const double old_log_weight = log(dim) - D.old_pll / dim;
+  // edge_log_weight, :160-162 (a landmark edge's division by 2 is an exact halving)
+  const double new_log_weight = log(dim) - (is_state ? D.new_pll / 3.0 : 0.5 * D.new_pll);
+  const double old_log_weight = log(dim) - (is_state ? D.old_pll / 3.0 : 0.5 * D.old_pll);
   double normaliser = 1.0;
   // a tempered replica targets controls x readings^beta: the readings' part of the ratio is
   // weighed by the inverse temperature; with beta = 1 this is log_ratio bit for bit
@@ -1582,6 +1638,7 @@ MG_DEV bool driver_finish_update(const Dev& d, uint32_t c, DriverState& D, R& rn
       D.llc += D.new_pll - D.old_pll;
       d.clp[size_t(c) * d.Tcap + D.idx] = D.new_pll;
       wt::set(sw, D.Tcur, D.idx, new_weight);
+      D.w_dirty |= kDirtyStates;
       // the relative pose itself is stored after commit_state_edge has moved
       // the pose table (that needs the old angle)
     } else {
@@ -1589,8 +1646,8 @@ MG_DEV bool driver_finish_update(const Dev& d, uint32_t c, DriverState& D, R& rn
       d.fex[fi] = D.q[0];
       d.fey[fi] = D.q[1];
       wt::set(fw, D.nf, D.idx, new_weight);
+      D.w_dirty |= kDirtyLandmarks;
     }
-    D.w_dirty = 1;
     D.ll += log_ratio;
   }
   write_trace(d, c, D, is_state ? 0 : 1, D.idx, D.q, log_ratio, accept ? 1 : 0);
@@ -1610,8 +1667,8 @@ struct FinishPrepared {
 #if defined(__HIP_DEVICE_COMPILE__)
 MG_DEV FinishPrepared finish_prepare(const TestInputs& in) {  // by a whole wavefront on the same data
   const double dim = in.is_state ? 3.0 : 2.0;
-  const double new_log_weight = log(dim) - in.new_pll / dim;
-  const double old_log_weight = log(dim) - in.old_pll / dim;
+  const double new_log_weight = log(dim) - (in.is_state ? in.new_pll / 3.0 : 0.5 * in.new_pll);
+  const double old_log_weight = log(dim) - (in.is_state ? in.old_pll / 3.0 : 0.5 * in.old_pll);
   const double e = exp((threadIdx.x & 63u) == 1 ? old_log_weight : new_log_weight);
   const double new_weight = wt::readlane_f64(e, 0), old_weight = wt::readlane_f64(e, 1);
   double normaliser = 1.0;
@@ -1638,13 +1695,14 @@ MG_DEV void finish_apply(const Dev& d, uint32_t c, DriverState& D, double new_we
       D.llc += D.new_pll - D.old_pll;
       d.clp[size_t(c) * d.Tcap + D.idx] = D.new_pll;
       wt::set(state_tree(d, c, D), D.Tcur, D.idx, new_weight);
+      D.w_dirty |= kDirtyStates;
     } else {
       const size_t fi = size_t(c) * d.Fcap + D.idx;
       d.fex[fi] = D.q[0];
       d.fey[fi] = D.q[1];
       wt::set(landmark_tree(d, c, D), D.nf, D.idx, new_weight);
+      D.w_dirty |= kDirtyLandmarks;
     }
-    D.w_dirty = 1;
     D.ll += log_ratio;
   }
   write_trace(d, c, D, is_state ? 0 : 1, D.idx, D.q, log_ratio, accept ? 1 : 0);
@@ -1679,7 +1737,7 @@ MG_DEV bool driver_arrival(const Dev& d, uint32_t c, DriverState& D, R& rng, uin
     keep_parent_pose(d, c, fi, t);
     d.flast[fi] = t;
     wt::push_back(landmark_tree(d, c, D), f, edge_weight_from_log_pdf(reading_proposal_log_pdf(m, est), 2.0, nullptr));
-    D.w_dirty = 1;
+    D.w_dirty |= kDirtyLandmarks;
     D.ll += reading_log_pdf(m, est);
     D.nf = f + 1;
     return false;
@@ -1709,6 +1767,7 @@ MG_DEV bool driver_arrival(const Dev& d, uint32_t c, DriverState& D, R& rng, uin
     D.q[2] = 0.0;
     D.pending = PEND_REPARENT;
     D.use_weight = 0;
+    D.list.valid = 0;
     D.rp_obs = o;
     return true;
   }
@@ -1833,11 +1892,12 @@ MG_DEV void chain_state_load(const Dev& d, uint32_t c, Shared& S, DriverState& D
     // prints "stuck in ... select loop" for ever, mcmc_slam.hpp:350-354) stays stopped: a later launch must
     // not spend its 65 536 redraws again (a replay queues one launch per timestep)
     D.failed = d.errflag[c];
-    D.w_dirty = 1;
+    D.w_dirty = kDirtyStates | kDirtyLandmarks;
     D.sw_top = D.fw_top = 0;
     D.sw_shift = D.fw_shift = 0;
     D.pending = PEND_NONE;
     D.spec_ready = 0;
+    D.list.valid = 0;
   }
 }
 MG_DEV void chain_state_store(const Dev& d, uint32_t c, Shared& S, const DriverState& D) {
@@ -1906,7 +1966,7 @@ MG_DEV void step_with(const Dev& d, uint32_t c, Shared& S, DriverState& D, R& rn
       wt::set(landmark_tree(d, c, D), D.nf, idx,
               edge_weight_from_log_pdf(reading_proposal_log_pdf(load_reading(d, o), Vec2{d.fex[fi], d.fey[fi]}), 2.0,
                                        nullptr));
-      D.w_dirty = 1;
+      D.w_dirty |= kDirtyLandmarks;
     }
     D.pending = PEND_NONE;
 #ifdef MG_PHASE_TIMING
@@ -2074,7 +2134,7 @@ MG_DEV void advance_ahead(DevArgs dp, SharedLds sp, uint32_t c, DriverState& D, 
           wt::set(landmark_tree(d, c, D), D.nf, idx,
                   edge_weight_from_log_pdf(reading_proposal_log_pdf(load_reading(d, o), Vec2{d.fex[fi], d.fey[fi]}), 2.0,
                                            nullptr));
-          D.w_dirty = 1;
+          D.w_dirty |= kDirtyLandmarks;
         }
         D.pending = PEND_NONE;
         if (D.op == OP_EVAL_STATE && accept) {
@@ -2343,6 +2403,22 @@ __global__ void __launch_bounds__(SOLO ? 256 : 1024) advance_kernel(Dev d, uint3
       continue;
     }
     unsigned long long units;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (SOLO && !RB && blockDim.x == 64 && op == OP_EVAL_FEATURE && D.list.valid) {
+      // the readings are in the lanes already (ListAhead): the stream's arithmetic per reading, one reduction
+      const ListAhead& L = D.list;
+      const Vec2 wo = act(L.parent, L.current), wn = act(L.parent, Vec2{qx, qy});
+      const double ro = range_of(wo.x - L.pose.x, wo.y - L.pose.y), rn = range_of(wn.x - L.pose.x, wn.y - L.pose.y);
+      const double term = (ro - rn) * fma(-2.0, L.mu, ro + rn) * L.k;
+      r = wave_prefix_sums((threadIdx.x & 63u) < L.count ? term : 0.0);  // lane 63: the sum
+      r = wt::readlane_f64(r, 63);
+      units = L.count;
+      D.n_units += units;
+      MG_STAMP(te1);
+      MG_PHASE_ADD(S, 3, td1, te1);
+      continue;
+    }
+#endif
     WholeBlock everyone;
     r = inline_eval<RB>(dp, sp, c, op, idx, qx, qy, qth, nf, units, everyone);
     if (SOLO || threadIdx.x == 0) {
