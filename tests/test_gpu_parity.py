@@ -188,6 +188,32 @@ def test_selection_ahead_of_time_matches_oracle(lanes, landmarks, k):
     assert_close(g.log_likelihood(), full, 1e-8, "incremental vs from-scratch log likelihood")
 
 
+@pytest.mark.parametrize("uniform_sigma", [True, False])
+def test_one_wavefront_per_chain_with_readings_fetched_ahead(uniform_sigma):
+    """64 lanes and the serial program compiled in -- what many chains on sparse data get by default: the
+    wavefront that draws a landmark proposal asks for the landmark's readings and their poses while it draws
+    (lists of at most 64; here 15 on average, growing from one as the chain grows) and evaluates them in
+    registers.  Online, step for step against the oracle, with one sigma for all readings and with a sigma per
+    reading (the per-reading factor is then fetched ahead as well)."""
+    p = synthetic.make_problem(T=300, n_landmarks=60, k_nearest=3, seed=23, lap_steps=140, wobble_period=450,
+                               range_stddev=2.0, landmark_spread=7.0)
+    if not uniform_sigma:
+        p = dict(p)
+        p["obs_std"] = p["obs_std"] * (1.0 + 0.3 * np.random.default_rng(4).random(p["N"]))
+    seeds = capi.seed_sequence(77, 3)
+    w = oracle_world(p, [int(x) for x in seeds], steps_per_timestep=3, end_steps=400)
+    w.replay(p["T"], finish=True)
+    g = gpu_handle(p, seeds, trace_capacity=4096, threads_per_chain=64, serial_program=2)
+    g.advance(p["T"], steps_per_timestep=3, end_steps=400)
+    g.sync()
+    upd, acc, units = g.counters()
+    for c in range(len(seeds)):
+        compare_traces(g.trace(c), w.trace(c))
+        assert_close(g.log_likelihood()[c], w.log_likelihood(c), REL, f"chain {c} final log likelihood")
+        assert units[c] == w.units(c), "evaluated-observation counts differ"
+    assert_close(g.log_likelihood(), g.full_log_likelihood(), 1e-8, "incremental vs from-scratch log likelihood")
+
+
 def test_online_in_pieces_equals_one_call():
     """Growing timestep by timestep with re-uploads of the growing problem gives the same chain."""
     p = small_problem(T=120, F=8, k=3, seed=5)
