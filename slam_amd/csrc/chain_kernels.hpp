@@ -326,6 +326,9 @@ struct Shared {
 #endif
   uint32_t wcount[kMaxWaves];
   double red[kMaxWaves];
+  // the four rigid motions of a state-edge proposal (ProposalFrames), kept here between the rounds of its
+  // evaluation: sixteen doubles held in registers across the reading stream cost it a spill
+  double frames[16];
   // advance_kernel's SPEC variant: the barrier of the wavefronts after the first (TailWaves), and what they
   // hand the first one when an evaluation is done: its number, its sum and the readings it went through
   uint32_t tail_arrivals, eval_arrived;
@@ -1125,7 +1128,20 @@ MG_DEV double eval_state_edge(const Dev& d, uint32_t c, Shared& S, uint32_t t, c
     MG_PHASE_ADD(S, 2, ts1, ts2);
     return tm.sum(sum, S);
   }
-  const ProposalFrames fr = proposal_frames(world_pose(d, c, t), world_pose(d, c, t + 1), q);
+  {
+    const ProposalFrames once = proposal_frames(world_pose(d, c, t), world_pose(d, c, t + 1), q);
+    if (tid == 0) {
+      const Frame* f4[4] = {&once.Pt, &once.Pt1, &once.q, &once.qinv};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        S.frames[4 * k] = f4[k]->x;
+        S.frames[4 * k + 1] = f4[k]->y;
+        S.frames[4 * k + 2] = f4[k]->c;
+        S.frames[4 * k + 3] = f4[k]->s;
+      }
+    }
+    tm.sync();
+  }
   double acc = 0.0;
 #ifdef MG_PHASE_TIMING
   long long tab = clock64();
@@ -1136,6 +1152,9 @@ MG_DEV double eval_state_edge(const Dev& d, uint32_t c, Shared& S, uint32_t t, c
     uint32_t slo = lo, len = 0;
     Vec2 w{0.0, 0.0}, wn{0.0, 0.0};
     if (affected) {
+      const double* fm = S.frames;
+      const ProposalFrames fr{Frame{fm[0], fm[1], fm[2], fm[3]}, Frame{fm[4], fm[5], fm[6], fm[7]},
+                              Frame{fm[8], fm[9], fm[10], fm[11]}, Frame{fm[12], fm[13], fm[14], fm[15]}};
       const uint32_t hi = lo + d.fcnt[fbase + f];
       const uint32_t pt = d.fpt[fbase + f];
       const Vec2 e{d.fex[fbase + f], d.fey[fbase + f]};

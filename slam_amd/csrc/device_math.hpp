@@ -542,8 +542,11 @@ struct SerialRng {
   RngState& st;
   MG_DEV double uniform() { return rng_uniform(st); }
   MG_DEV double normal() { return rng_normal(st); }
-  MG_DEV void normals(double* out, int count) {
-    for (int i = 0; i < count; ++i) out[i] = rng_normal(st);
+  MG_DEV void normals(double* out, int count) {  // count <= 4; written out so that `out` stays in registers
+    if (count > 0) out[0] = rng_normal(st);
+    if (count > 1) out[1] = rng_normal(st);
+    if (count > 2) out[2] = rng_normal(st);
+    if (count > 3) out[3] = rng_normal(st);
   }
   MG_DEV void flush() {}
 };
