@@ -2970,16 +2970,15 @@ __global__ void __launch_bounds__(kScanLanes) scan_chain_kernel(ScanArgs a) {
 // ---- the same scan in ONE pass over memory, for few long chains ------------------------------------
 // The two-pass form above reads every relative pose twice (72 bytes of traffic per pose instead of 48).
 // Here a chain is cut into pieces of kPieceTiles tiles whose scanned poses a workgroup can keep in
-// registers: it scans its piece relative to the piece's start, publishes the piece's total, collects the
-// totals of ALL pieces before it in its chain (they are produced independently of each other, so nobody
-// waits for a chain of hand-overs), composes them in a fixed order -- oldest first, 64 at a time -- and
+// registers: it scans its piece relative to the piece's start, publishes the piece's total, composes the
+// totals of the pieces before it in its chain in a fixed order -- oldest first, 64 at a time -- and
 // places its poses.  The order of compositions depends on the piece's number only, not on timing, so two
-// rebuilds of the same data give the same bits.  Pieces are handed out by a ticket counter, chain after
-// chain and piece after piece: a workgroup only ever waits for pieces with lower tickets, which are
-// running or done.  The look-back is quadratic in the pieces of a chain (piece p reads p totals), which
-// is nothing against the poses up to kPieceMaxPerChain pieces; longer chains keep the two-pass form.
+// rebuilds of the same data give the same bits.  Pieces are handed out by a ticket counter: a workgroup
+// only ever waits for pieces with lower tickets, which are running or done.  Reading ALL earlier totals
+// would be quadratic in the pieces of a chain (at 326 pieces a third as many memory transactions again as
+// the poses themselves), so the prefix is handed on once per window of 64 pieces; see the kernel.
 constexpr int kPieceTiles = 3;                 // 3072 poses per piece, 12 per lane
-constexpr uint32_t kPieceMaxPerChain = 1024;   // look-back reads at most this many totals per piece
+constexpr uint32_t kPieceMaxPerChain = 1024;   // at most 16 hand-overs of the prefix along a chain
 // A piece's total (x, y, cos, sin, angle) as five 64-bit words, each written and read by one device-wide
 // atomic access of its own.  Before the launch every word holds kPieceEmpty (all ones: a NaN no total
 // contains); a reader takes a total once none of its five words is that any more.  No word waits for
@@ -2993,6 +2992,33 @@ static_assert(sizeof(PieceSlot) == 48, "piece slots are 48 bytes");
 constexpr unsigned long long kPieceEmpty = ~0ull;
 constexpr uint32_t kPieceHeaderBytes = 256;  // the scratch starts with the ticket counter
 
+__device__ __forceinline__ void publish_piece_word(unsigned long long* word, double part) {
+  unsigned long long bits = (unsigned long long)__double_as_longlong(part);
+  // (input that carries this very NaN through the arithmetic must not look like an empty slot: readers would wait for ever)
+  if (bits == kPieceEmpty) bits = 0x7FF8000000000000ull;
+  __hip_atomic_store(word, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ PoseCS read_piece_slot(const PieceSlot* sl) {
+  unsigned long long w[5];
+  for (;;) {
+    bool full = true;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      w[k] = __hip_atomic_load(&sl->word[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      full = full && w[k] != kPieceEmpty;
+    }
+    if (full) break;
+    __builtin_amdgcn_s_sleep(2);
+  }
+  return PoseCS{__longlong_as_double((long long)w[0]), __longlong_as_double((long long)w[1]), __longlong_as_double((long long)w[2]),
+                __longlong_as_double((long long)w[3]), __longlong_as_double((long long)w[4])};
+}
+// Slots the scratch holds behind its header for `chains` chains of `pieces` pieces: one per piece, then one
+// per window of 64 pieces and chain for the prefix at that window's start.
+__host__ __device__ constexpr uint64_t piece_slots_needed(uint64_t chains, uint64_t pieces) {
+  return chains * (pieces + (pieces + 63) / 64);
+}
+
 // a.nseg = pieces per chain, a.seg_len = kPieceTiles tiles; `scratch` = [ticket = 0][chains * nseg slots of kPieceEmpty].
 __global__ void __launch_bounds__(kScanLanes) scan_pieces_kernel(ScanArgs a, unsigned char* scratch) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -3002,9 +3028,17 @@ __global__ void __launch_bounds__(kScanLanes) scan_pieces_kernel(ScanArgs a, uns
   __shared__ uint32_t my_ticket;
   uint32_t* ticket = reinterpret_cast<uint32_t*>(scratch);
   PieceSlot* slots = reinterpret_cast<PieceSlot*>(scratch + kPieceHeaderBytes);
-  if (threadIdx.x == 0) my_ticket = atomicAdd(ticket, 1u);
+  if (threadIdx.x == 0) my_ticket = atomicAdd(ticket, 1u) + 1u;  // the counter starts at all ones like the rest of the scratch
   __syncthreads();
-  const uint32_t c = my_ticket / a.nseg, piece = my_ticket % a.nseg;
+  // Tickets run piece after piece across the chains when a chain has more than one window of pieces, so
+  // that the pieces in flight belong to many chains and few of them wait for a prefix to be handed on;
+  // chain after chain otherwise.  Either way a workgroup only waits for lower tickets.
+  const uint32_t chains = gridDim.x / a.nseg;
+  const bool across = a.nseg > 64 || gridDim.x < 16384u;
+  const uint32_t c = across ? my_ticket % chains : my_ticket / a.nseg;
+  const uint32_t piece = across ? my_ticket / chains : my_ticket % a.nseg;
+  const uint32_t windows_per_chain = (a.nseg + 63) / 64;
+  PieceSlot* prefixes = slots + size_t(chains) * a.nseg;
   const uint32_t tile = uint32_t(kScanLanes) * K;
   const uint32_t lo = piece * a.seg_len;
   const uint32_t hi = a.n - lo < a.seg_len ? a.n : lo + a.seg_len;
@@ -3069,40 +3103,25 @@ __global__ void __launch_bounds__(kScanLanes) scan_pieces_kernel(ScanArgs a, uns
     }
   }
   // `all` is the piece's total: publish it, then collect what lies before the piece
-  PieceSlot* mine_slot = slots + size_t(c) * a.nseg + piece;
-  if (threadIdx.x < 5) {
-    const double part = threadIdx.x == 0 ? all.x : threadIdx.x == 1 ? all.y : threadIdx.x == 2 ? all.c : threadIdx.x == 3 ? all.s : all.th;
-    unsigned long long bits = (unsigned long long)__double_as_longlong(part);
-    // (input that carries this very NaN through the arithmetic must not look like an empty slot: readers would wait for ever)
-    if (bits == kPieceEmpty) bits = 0x7FF8000000000000ull;
-    __hip_atomic_store(&mine_slot->word[threadIdx.x], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  if (threadIdx.x < 5)
+    publish_piece_word(&slots[size_t(c) * a.nseg + piece].word[threadIdx.x],
+                       threadIdx.x == 0 ? all.x : threadIdx.x == 1 ? all.y : threadIdx.x == 2 ? all.c : threadIdx.x == 3 ? all.s : all.th);
+  // What lies before the piece: the prefix of its chain up to the start of a window of 64 pieces, which
+  // the first piece of the NEXT window has published (it needs that very value itself), composed with
+  // the totals of the pieces from there on -- at most 64, one per lane.  So a piece reads at most 65
+  // slots however long its chain is, and the compositions are the same whoever runs when.
   if (wave == 0) {
+    const uint32_t base = piece == 0 ? 0u : ((piece - 1) & ~63u);  // a window's first piece looks back over the whole window before it
     PoseCS prefix = op.identity();
-    const PieceSlot* chain_slots = slots + size_t(c) * a.nseg;
-    for (uint32_t w0 = 0; w0 < piece; w0 += 64) {  // pieces w0 .. w0 + 63 of this chain, oldest window first
-      PoseCS v = op.identity();
-      const uint32_t q = w0 + lane;
-      if (q < piece) {
-        const PieceSlot* sl = chain_slots + q;
-        unsigned long long w[5];
-        for (;;) {
-          bool full = true;
-#pragma unroll
-          for (int k = 0; k < 5; ++k) {
-            w[k] = __hip_atomic_load(&sl->word[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            full = full && w[k] != kPieceEmpty;
-          }
-          if (full) break;
-          __builtin_amdgcn_s_sleep(2);
-        }
-        v = PoseCS{__longlong_as_double((long long)w[0]), __longlong_as_double((long long)w[1]), __longlong_as_double((long long)w[2]),
-                   __longlong_as_double((long long)w[3]), __longlong_as_double((long long)w[4])};
-      }
-      const PoseCS inc = wave_scan_inclusive(v, op);  // identities behind the last piece change nothing
-      const PoseCS window = PoseCS{__shfl(inc.x, 63), __shfl(inc.y, 63), __shfl(inc.c, 63), __shfl(inc.s, 63), __shfl(inc.th, 63)};
-      prefix = op(prefix, window);
-    }
+    if (base > 0) prefix = read_piece_slot(prefixes + size_t(c) * windows_per_chain + (base >> 6));
+    PoseCS v = op.identity();
+    if (base + lane < piece) v = read_piece_slot(slots + size_t(c) * a.nseg + base + lane);
+    const PoseCS inc = wave_scan_inclusive(v, op);  // identities behind the last piece change nothing
+    const PoseCS window = PoseCS{__shfl(inc.x, 63), __shfl(inc.y, 63), __shfl(inc.c, 63), __shfl(inc.s, 63), __shfl(inc.th, 63)};
+    prefix = op(prefix, window);
+    if (piece > 0 && (piece & 63u) == 0 && lane < 5)
+      publish_piece_word(&prefixes[size_t(c) * windows_per_chain + (piece >> 6)].word[lane],
+                         lane == 0 ? prefix.x : lane == 1 ? prefix.y : lane == 2 ? prefix.c : lane == 3 ? prefix.s : prefix.th);
     if (lane == 0) before_piece = prefix;
   }
   __syncthreads();

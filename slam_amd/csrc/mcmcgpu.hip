@@ -437,7 +437,7 @@ ScanPlan scan_plan(uint32_t chains, uint32_t n) {
     // the scratch (the handle's and the static one are the same size, so both entry points plan alike)
     const uint32_t piece_len = uint32_t(kPieceTiles) * tile;
     const uint64_t pieces = (uint64_t(n) + piece_len - 1) / piece_len;
-    if (pieces <= kPieceMaxPerChain && kPieceHeaderBytes + uint64_t(chains) * pieces * sizeof(PieceSlot) <= kScanScratchBytes)
+    if (pieces <= kPieceMaxPerChain && kPieceHeaderBytes + piece_slots_needed(chains, pieces) * sizeof(PieceSlot) <= kScanScratchBytes)
       return ScanPlan{uint32_t(pieces), piece_len, true};
   }
   return ScanPlan{nseg, seg_len, false};
@@ -450,10 +450,8 @@ hipError_t launch_scan(hipStream_t stream, ScanArgs a, uint32_t chains, bool sin
   if (chains == 0) return hipSuccess;
   if (single_pass) {  // `tot` is the whole scratch: ticket counter and piece slots, cleared for this launch
     unsigned char* scratch_bytes = reinterpret_cast<unsigned char*>(a.tot);
-    const size_t used = kPieceHeaderBytes + size_t(chains) * a.nseg * sizeof(PieceSlot);
-    if (hipError_t e = hipMemsetAsync(scratch_bytes, 0, kPieceHeaderBytes, stream); e != hipSuccess) return e;
-    if (hipError_t e = hipMemsetAsync(scratch_bytes + kPieceHeaderBytes, 0xFF, used - kPieceHeaderBytes, stream); e != hipSuccess)
-      return e;
+    const size_t used = kPieceHeaderBytes + size_t(piece_slots_needed(chains, a.nseg)) * sizeof(PieceSlot);
+    if (hipError_t e = hipMemsetAsync(scratch_bytes, 0xFF, used, stream); e != hipSuccess) return e;
     hipLaunchKernelGGL(scan_pieces_kernel, dim3(chains * a.nseg), dim3(kScanLanes), 0, stream, a, scratch_bytes);
     return hipGetLastError();
   }

@@ -296,10 +296,12 @@ def test_rebuild_scan_matches_oracle_accumulate():
     assert_close(g.get_state(0)["cum"], grown, 1e-11, "scan vs poses appended one by one")
 
 
-@pytest.mark.parametrize("T,chains", [(20000, 2), (9000, 3), (5000, 1)])
+@pytest.mark.parametrize("T,chains", [(20000, 2), (9000, 3), (5000, 1), (260000, 2), (400000, 1)])
 def test_rebuild_scan_in_segments_matches_oracle_accumulate(T, chains):
-    """Few chains on a long trajectory: the rebuild cuts every chain into segments (one workgroup each, totals,
-    offsets, second pass); against bitree<pose>::accumulate of the oracle, every chain its own trajectory."""
+    """Few chains on a long trajectory: the rebuild cuts every chain into pieces, one workgroup each, which pass
+    on what lies before them (the two longest cases: more than 64 pieces per chain, so the prefix is handed on
+    from window to window and tickets run across the chains); against bitree<pose>::accumulate of the oracle,
+    every chain its own trajectory."""
     p = synthetic.make_problem(T=T, n_landmarks=12, k_nearest=3, seed=T, lap_steps=400, wobble_period=900,
                                range_stddev=1.0, landmark_spread=8.0)
     seeds = capi.seed_sequence(T, chains)
