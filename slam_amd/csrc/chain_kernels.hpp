@@ -1552,6 +1552,9 @@ MG_DEV int begin_update_core(const Dev& d, uint32_t c, Shared& S, DriverState& D
 #if defined(__HIP_DEVICE_COMPILE__)
     // ... and the pose it was taken at between the draws and the proposal's densities
     D.list.valid = 0;
+    // (every earlier load has come back before the pose is asked for: where the two paths meet again, the
+    // compiler would otherwise wait for "whatever is outstanding" at the next use of any of them -- the pose)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     if (list_fits) {
       asm volatile("" ::"v"(list_rec.t), "v"(list_rec.mu), "v"(list_k));
       D.list.pose = d.pxy[size_t(c) * (d.Tcap + 1) + list_rec.t];
@@ -2375,6 +2378,7 @@ __global__ void __launch_bounds__(SOLO ? 256 : 1024) advance_kernel(Dev d, uint3
   __syncthreads();
   MG_STAMP(tk0);
   double r = 0.0;
+  const bool lone = SOLO && blockDim.x == 64;  // the chain's only wavefront runs the program AND evaluates
 #if defined(__HIP_DEVICE_COMPILE__)
   WaveRng wave_rng(S.rng);  // used by the first wavefront of the SOLO variant only
   if (SPEC) {
@@ -2387,7 +2391,7 @@ __global__ void __launch_bounds__(SOLO ? 256 : 1024) advance_kernel(Dev d, uint3
 #if defined(__HIP_DEVICE_COMPILE__)
       if (threadIdx.x < 64) {  // the first wavefront, all lanes on the same data
         step_body_wave(dp, sp, c, r, wave_rng, D);
-        if (threadIdx.x == 0) {  // the request, where the other wavefronts find it
+        if (threadIdx.x == 0 && !lone) {  // the request, where the other wavefronts find it
           S.drv.op = D.op;
           S.drv.idx = D.idx;
           S.drv.q[0] = D.q[0];
@@ -2401,14 +2405,15 @@ __global__ void __launch_bounds__(SOLO ? 256 : 1024) advance_kernel(Dev d, uint3
     } else {
       if (threadIdx.x == 0) piece_step(dp, sp, c, r);
     }
-    __syncthreads();
+    if (!lone) __syncthreads();
     MG_STAMP(td1);
     MG_PHASE_ADD(S, 0, td0, td1);
-    const int op = S.drv.op;
+    // (a lone wavefront has the request in its registers: nothing to hand over, nobody to wait for)
+    const int op = lone ? D.op : S.drv.op;
     if (op == OP_END) break;
-    const uint32_t idx = S.drv.idx;
-    const double qx = S.drv.q[0], qy = S.drv.q[1], qth = S.drv.q[2];
-    const uint32_t Tcur = S.drv.Tcur, nf = S.drv.nf;
+    const uint32_t idx = lone ? D.idx : S.drv.idx;
+    const double qx = lone ? D.q[0] : S.drv.q[0], qy = lone ? D.q[1] : S.drv.q[1], qth = lone ? D.q[2] : S.drv.q[2];
+    const uint32_t Tcur = lone ? D.Tcur : S.drv.Tcur, nf = lone ? D.nf : S.drv.nf;
     if (op == OP_COMMIT) {  // the state edge just accepted: all lanes move the pose table, then lane 0 goes on
       if (SOLO) {
         WholeBlock everyone;
@@ -2423,8 +2428,24 @@ __global__ void __launch_bounds__(SOLO ? 256 : 1024) advance_kernel(Dev d, uint3
     }
     unsigned long long units;
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (SOLO && !RB && blockDim.x == 64 && op == OP_EVAL_FEATURE && D.list.valid) {
-      // the readings are in the lanes already (ListAhead): the stream's arithmetic per reading, one reduction
+    if (SOLO && !RB && lone && op == OP_EVAL_FEATURE && D.list.valid) {
+      // The readings are in the lanes already (ListAhead), all but the poses they were taken at, which are
+      // still on their way: the accept test is prepared meanwhile -- its uniform (nothing else draws between
+      // a proposal and that uniform, mcmc_slam.hpp:375-408), the two edge weights, the normaliser -- then the
+      // stream's arithmetic per reading and one reduction, the decision and what it changes: step_with's
+      // first half, here because the test's first part must come BEFORE the evaluation to overlap anything.
+      TestInputs test;
+      test.u = wave_rng.uniform();
+      if (D.use_weight) refresh_totals(d, c, D);
+      test.is_state = 0;
+      test.use_weight = D.use_weight;
+      test.new_pll = D.new_pll;
+      test.old_pll = D.old_pll;
+      test.beta = D.beta;
+      test.weight_sum = D.Ws + D.Wf;
+      const FinishPrepared pre = finish_prepare(test);
+      MG_STAMP(tp1);
+      MG_PHASE_ADD(S, 4, td1, tp1);
       const ListAhead& L = D.list;
       const Vec2 wo = act(L.parent, L.current), wn = act(L.parent, Vec2{qx, qy});
       const double ro = range_of(wo.x - L.pose.x, wo.y - L.pose.y), rn = range_of(wn.x - L.pose.x, wn.y - L.pose.y);
@@ -2434,7 +2455,15 @@ __global__ void __launch_bounds__(SOLO ? 256 : 1024) advance_kernel(Dev d, uint3
       units = L.count;
       D.n_units += units;
       MG_STAMP(te1);
-      MG_PHASE_ADD(S, 3, td1, te1);
+      MG_PHASE_ADD(S, 3, tp1, te1);
+      const bool accept = finish_decide(test, pre, r);
+      finish_apply(d, c, D, pre.new_weight, r, accept);
+      D.awaiting = 0;  // (the list is fetched for plain updates only: no re-parenting to undo)
+      D.accept = accept ? 1 : 0;
+      if (accept) ++D.n_acc;
+      D.pending = PEND_NONE;
+      MG_STAMP(tf1);
+      MG_PHASE_ADD(S, 4, te1, tf1);
       continue;
     }
 #endif

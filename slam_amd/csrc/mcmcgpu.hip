@@ -401,8 +401,8 @@ TreeTops plan_tree_tops(const mcmcgpu_ctx* h, uint32_t state_nodes) {
   const auto held = [](uint32_t nodes, uint32_t shift) { return nodes ? size_t((nodes - 1) >> shift) + 1 : size_t(0); };
   const uint32_t F = h->d.F;
   uint32_t fs = 0;
-  while (fs < 12 && held(F, fs) > budget / 3) ++fs;
-  if (held(F, fs) <= budget / 3) {
+  while (fs < 12 && held(F, fs) > budget / 2) ++fs;
+  if (held(F, fs) <= budget / 2) {
     t.fw_shift = fs;
     t.fw_n = uint32_t(held(F, fs));
   }
