@@ -344,7 +344,8 @@ int lay_out(mcmcgpu_handle h, bool with_slack) {
 constexpr uint32_t kStaticScanChains = 4096;  // most chains one mcmcgpu_scan_poses_static call takes
 constexpr uint32_t kStaticScanMaxPoses = 0xFFFF0000u;  // and most relative poses per chain
 // One MiB: the two-pass scan's segment totals ((1024 + 4096) x 24 bytes at most) or the single-pass scan's
-// ticket and piece slots (256 + 48 bytes per piece of 4096 poses: 64 chains of 1 000 000 poses take 750 KB).
+// ticket and slots (256 bytes, then 48 per piece of 3072 poses and 48 per window of 64 pieces: 64 chains of
+// 1 000 000 poses take 1 020 160 bytes).
 constexpr size_t kScanScratchBytes = size_t(1) << 20;
 constexpr size_t kStaticScratchBytes = kScanScratchBytes;
 static_assert((size_t(kScanTargetGroups) + kStaticScanChains) * sizeof(Pose) <= kScanScratchBytes, "two-pass totals fit");
@@ -387,8 +388,10 @@ static_assert(sizeof(Shared) <= kAdvanceStaticLds, "advance_kernel's static LDS 
 // Copies of the weight trees' tops for one launch of advance_kernel: every node whose index is a
 // multiple of 2^shift, with the smallest shifts whose copies fit into the LDS left beside the
 // workgroups that share a CU (as many as the chain count and the kernel's 128 registers allow).
-// One chain alone on a CU keeps a Plaza-sized tree whole; 1024 chains of 100 000 poses keep every
-// 64th node of the state tree and the whole landmark tree.
+// The landmark tree comes first and may take half (most proposals are a landmark's where landmarks are
+// many, and a tree held whole is searched without a look at memory).  One chain alone on a CU keeps a
+// Plaza-sized tree whole; 1024 chains of 100 000 poses and 1000 landmarks keep the whole landmark tree and
+// every 128th node of the state tree.
 TreeTops plan_tree_tops(const mcmcgpu_ctx* h, uint32_t state_nodes) {
   const uint32_t waves = h->nthreads / 64;
   const uint32_t by_registers = std::max<uint32_t>(1, 16 / waves);  // 4 wavefronts per SIMD at 128 registers
@@ -448,7 +451,7 @@ size_t scan_total_slots(size_t chains) { return kScanTargetGroups + chains; }
 // The scan's launches on `stream`; `tot` must hold chains * plan.nseg poses when plan.nseg > 1.
 hipError_t launch_scan(hipStream_t stream, ScanArgs a, uint32_t chains, bool single_pass) {
   if (chains == 0) return hipSuccess;
-  if (single_pass) {  // `tot` is the whole scratch: ticket counter and piece slots, cleared for this launch
+  if (single_pass) {  // `tot` is the whole scratch: ticket counter and slots, every byte set to 0xFF for this launch
     unsigned char* scratch_bytes = reinterpret_cast<unsigned char*>(a.tot);
     const size_t used = kPieceHeaderBytes + size_t(piece_slots_needed(chains, a.nseg)) * sizeof(PieceSlot);
     if (hipError_t e = hipMemsetAsync(scratch_bytes, 0xFF, used, stream); e != hipSuccess) return e;
