@@ -12,7 +12,11 @@ from test_gpu_parity import REL, assert_close, compare_traces, gpu_handle, small
 pytestmark = pytest.mark.gpu
 
 
-def test_heated_chains_match_oracle():
+@pytest.mark.parametrize("lanes,serial_program", [(0, 0), (64, 2), (128, 3)])
+def test_heated_chains_match_oracle(lanes, serial_program):
+    """Library defaults; one wavefront per chain with the serial program compiled in (a landmark proposal's
+    accept test is then prepared before its evaluation, in two parts that both use the temperature); and two
+    wavefronts with the next update selected ahead (the test decided by the evaluating wavefront)."""
     p = small_problem()
     betas = np.array([1.0, 0.5, 0.1, 0.02])
     seeds = capi.seed_sequence(515, len(betas))
@@ -22,7 +26,7 @@ def test_heated_chains_match_oracle():
     for s in seeds:
         w.add_chain(int(s), trace=True)
     w.replay(p["T"])
-    g = gpu_handle(p, seeds, trace_capacity=4096)
+    g = gpu_handle(p, seeds, trace_capacity=4096, threads_per_chain=lanes, serial_program=serial_program)
     g.grow(p["T"])
     g.set_ladders(betas, exchange_seed=1)
     beta, slot, _, att, swp = g.ladders()
